@@ -1,0 +1,114 @@
+/*
+ * roma_hip.h — C ABI of libroma_hip.so: the MI355X (gfx950) kernels behind the RoMa dense-matching hot path
+ * `RegressionMatcher.match()`.
+ *
+ * The reference (techshoww/RoMa) is pure Python/PyTorch and has NO FFI of its own; its seams are the Python call
+ * signatures listed in SURVEY.md §8(b).  Every entry point below replaces the chain of stock ATen ops behind one of
+ * those seams and cites it (file:line under the reference root).  A maintainer binds them with `ctypes`
+ * (INTEGRATION.md shows the stubs); roma_amd/_lib.py is that binding for this repository.
+ *
+ * Conventions
+ *   - plain C: pointers, ints, floats.  No torch / C++ types cross the boundary.
+ *   - every pointer is DEVICE memory owned by the caller; the library allocates nothing and keeps no state
+ *     except a thread-local error string.
+ *   - every launch is asynchronous on `stream` (a hipStream_t passed as void*; NULL = the default stream).
+ *   - return 0 = ok; <0 = bad argument (ROMA_E_*), roma_last_error() has the text; >0 = a hipError_t.
+ *   - dtype codes ROMA_F32/F16/BF16 describe feature/logit storage; accumulation is always fp32.
+ *     flow / certainty maps are always fp32 (as in the reference, matcher.py:141,397-402).
+ *   - feature layouts: ROMA_NCHW = (B,C,H,W) contiguous; ROMA_NHWC = (B,H,W,pitch) with the C channels of interest
+ *     starting at the pointer and `pitch` >= C elements between consecutive pixels (so a channel slice of a wider
+ *     channels-last buffer — e.g. the ConvRefiner concat buffer — can be read or written in place).
+ *     For ROMA_NCHW `pitch` is the number of channels of the enclosing (B,pitch,H,W) buffer.
+ */
+#ifndef ROMA_HIP_H
+#define ROMA_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ROMA_ABI_VERSION 1
+
+enum { ROMA_F32 = 0, ROMA_F16 = 1, ROMA_BF16 = 2 };
+enum { ROMA_NCHW = 0, ROMA_NHWC = 1 };
+enum { ROMA_E_ARG = -1, ROMA_E_DTYPE = -2, ROMA_E_SHAPE = -3, ROMA_E_ALIGN = -4, ROMA_E_UNSUPPORTED = -5 };
+
+int roma_abi_version(void);
+const char* roma_last_error(void);
+
+/* local_correlation — romatch/utils/local_correlation.py:4-48, called from ConvRefiner.forward (matcher.py:121-125).
+ *   out[b,k,y,x] = C^-1/2 * sum_c f0[b,c,y,x] * bilinear(f1[b,c], flow[b,:,y,x] + delta_k),  zeros padding,
+ *   align_corners=False, k = iy*(2r+1)+ix, delta_k = ((ix-r)*2/W, (iy-r)*2/H).
+ *   flow: (B,2,H,W) fp32 planar, (x,y) in [-1,1]; NULL = identity grid (local_correlation.py:16-27).
+ *   f0,f1: `dtype`, `layout`, pitches f0_pitch/f1_pitch.  out: K=(2r+1)^2 channels, `dtype`, out_layout/out_pitch.
+ *   r in {1..7}. */
+int roma_local_corr(const void* f0, const void* f1, const float* flow, void* out,
+                    int B, int C, int H, int W, int r, int dtype,
+                    int layout, int f0_pitch, int f1_pitch, int out_layout, int out_pitch, void* stream);
+
+/* F.grid_sample(y, flow^T, mode=bilinear, padding zeros, align_corners=False) — matcher.py:109 (ConvRefiner warp),
+ * tiny.py:357,363.  src: (B,C,Hs,Ws); flow (B,2,H,W) fp32 planar; dst: (B,C,H,W).  Layout/pitch rules as above. */
+int roma_warp_bilinear(const void* src, const float* flow, void* dst,
+                       int B, int C, int Hs, int Ws, int H, int W, int dtype,
+                       int layout, int src_pitch, int dst_layout, int dst_pitch, void* stream);
+
+/* displacement embedding — matcher.py:111-120: emb = Conv1x1(2->E)(gain * (flow - identity_grid)), gain = 40/32*scale_factor.
+ *   weight (E,2) fp32, bias (E) fp32, flow (B,2,H,W) fp32, dst E channels of `dtype` in dst_layout/dst_pitch. */
+int roma_disp_emb(const float* flow, const float* weight, const float* bias, void* dst,
+                  int B, int E, int H, int W, float gain, int dtype, int dst_layout, int dst_pitch, void* stream);
+
+/* F.interpolate(x, size=(Ho,Wo), mode="bilinear", align_corners=False) on fp32 planar maps — matcher.py:349-360,
+ * 408-417, 657-659.  x: (N,Hi,Wi) planes, y: (N,Ho,Wo).  Optional fused flow update of Decoder.forward
+ * (matcher.py:397-399): not here; see roma_flow_update. */
+int roma_interp_bilinear(const float* x, float* y, int N, int Hi, int Wi, int Ho, int Wo, void* stream);
+
+/* Decoder.forward update step — matcher.py:397-402:
+ *   flow[b,0] += ins*delta[b,0]/(4*Wf); flow[b,1] += ins*delta[b,1]/(4*Hf); cert[b] += delta[b,2]
+ *   delta: (B,3,H,W) fp32 planar (the refiner's out_conv result); cert may be NULL-initialised via cert_in==NULL (=0). */
+int roma_flow_update(float* flow, float* cert, const float* cert_in, const float* delta,
+                     int B, int H, int W, float sx, float sy, void* stream);
+
+/* cls_to_flow_refine — romatch/utils/utils.py:301-323 (softmax over res^2 anchors, mode, 5-point refinement with
+ * CLAMPED neighbour indices).  logits element (b, c, p) at logits[b*stride_b + c*stride_c + p*stride_p], p = y*W+x,
+ * C = res*res classes (C a multiple of 64).  flow out: (B,2,H,W) fp32 planar (the caller's permute(0,3,1,2),
+ * matcher.py:383-385).  If cert_out != NULL the extra logit c == C (transformer/__init__.py:45) is copied to
+ * cert_out (B,1,H,W) fp32. */
+int roma_cls_to_flow_refine(const void* logits, float* flow_out, float* cert_out,
+                            int B, int C, int HW, long stride_b, long stride_c, long stride_p,
+                            int dtype, void* stream);
+
+/* CosKernel — matcher.py:154-163:  K[b,n,m] = exp((<x_n,y_m>/(|x_n||y_m| + eps) - 1)/T), fp32 in / fp32 out on the
+ * exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).  x: (B,N,D) row-major, y: (B,M,D) row-major, K: (B,N,M).
+ * D a multiple of 16.  `diag_add` is added to K[b,i,i] when x == y (GP.forward's K_yy + sigma*I, matcher.py:259-261). */
+int roma_cos_kernel(const float* x, const float* y, float* K, int B, int N, int M, int D,
+                    float T, float eps, float diag_add, void* stream);
+
+/* match() post-processing — matcher.py:656-662, 684-718: certainty attenuation by the coarse scale-16 certainty,
+ * sigmoid, zeroing where |flow|>1, clamp, symmetric concat.
+ *   flow (2P,2,H,W), cert (2P,1,H,W) fp32 planar: first P = A->B, last P = B->A (forward_symmetric, matcher.py:516-528)
+ *   cert16 (2P,1,H16,W16) or NULL (no attenuation).
+ *   warp (P,H,2W,4) fp32, certainty (P,H,2W) fp32.   symmetric=0: flow (P,..), warp (P,H,W,4), certainty (P,H,W). */
+int roma_match_finalize(const float* flow, const float* cert, const float* cert16, float* warp, float* certainty,
+                        int P, int H, int W, int H16, int W16, int symmetric, void* stream);
+
+/* kde — romatch/utils/kde.py:4-12: density[i] = sum_j exp(-|x_i - x_j|^2 / (2 std^2)), x: (N,4) fp32 (already
+ * rounded to fp16 values by the caller when half=True), ref points every `down`-th row.  density (N) fp32. */
+int roma_kde_density(const float* x, float* density, int N, int down, float std, void* stream);
+
+/* ConvRefiner block front half — matcher.py:77-103 (create_block: depthwise 5x5 conv, BatchNorm(eval), ReLU),
+ * fused, channels-last.  BN is folded by the caller: y = relu(dwconv(x, w) * scale + shift).
+ *   x,y: (B,H,W,pitch) `dtype`; w: (25, C) fp32 tap-major; scale, shift: (C) fp32. */
+int roma_dwconv5x5_bn_relu(const void* x, const float* w, const float* scale, const float* shift, void* y,
+                           int B, int C, int H, int W, int dtype, int x_pitch, int y_pitch, void* stream);
+
+/* TinyRoMa corr_volume + pos_embed fused — tiny.py:241-254, 178-203: for every source pixel the soft-argmax target
+ * coordinate over the full correlation row, without materialising the (H1W1 x H0W0) volume.
+ *   f0: (B,H0*W0,C), f1: (B,H1*W1,C) row-major fp32 (C a multiple of 16); out (B,2,H0,W0) fp32.
+ *   exact != 0: full softmax expectation (tiny.py:201-202); exact == 0: reference fast path (tiny.py:187-198). */
+int roma_tiny_corr_posembed(const float* f0, const float* f1, float* out, int B, int C,
+                            int H0, int W0, int H1, int W1, int exact, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ROMA_HIP_H */

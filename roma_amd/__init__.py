@@ -1,0 +1,3 @@
+"""roma_amd — MI355X-native dense-matching inference path with the reference's Python surface
+(`roma_outdoor`, `roma_indoor`, `tiny_roma_v1_outdoor`, `.match/.sample/...`; romatch/__init__.py:2)."""
+from . import ops  # noqa: F401

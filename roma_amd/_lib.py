@@ -1,0 +1,67 @@
+"""ctypes binding of libroma_hip.so (include/roma_hip.h).  Loading never falls back: a missing library is an error."""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_long, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libroma_hip.so")
+
+ROMA_F32, ROMA_F16, ROMA_BF16 = 0, 1, 2
+ROMA_NCHW, ROMA_NHWC = 0, 1
+ABI_VERSION = 1
+
+# name -> argtypes; restype is c_int unless listed in _RESTYPES.  Mirrors include/roma_hip.h one to one.
+SIGNATURES = {
+    "roma_abi_version": [],
+    "roma_last_error": [],
+    "roma_local_corr": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                        c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "roma_warp_bilinear": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                           c_int, c_int, c_int, c_int, c_void_p],
+    "roma_disp_emb": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_int, c_void_p],
+    "roma_interp_bilinear": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "roma_flow_update": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p],
+    "roma_cls_to_flow_refine": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_long, c_long, c_int, c_void_p],
+    "roma_cos_kernel": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_void_p],
+    "roma_match_finalize": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "roma_kde_density": [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
+    "roma_dwconv5x5_bn_relu": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "roma_tiny_corr_posembed": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+}
+_RESTYPES = {"roma_last_error": c_char_p}
+
+_lib = None
+
+
+class RomaHipError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load libroma_hip.so (once).  Raises if it has not been built — there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RomaHipError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           f"or `make -C roma_amd/csrc`.  roma_amd has no CPU/PyTorch fallback for its kernels.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, c_int)
+    if lib.roma_abi_version() != ABI_VERSION:
+        raise RomaHipError(f"libroma_hip.so ABI {lib.roma_abi_version()} != binding ABI {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc == 0:
+        return
+    msg = load().roma_last_error().decode(errors="replace")
+    if rc < 0:
+        raise ValueError(f"{what}: {msg} (code {rc})")
+    raise RomaHipError(f"{what}: HIP error {rc}: {msg}")

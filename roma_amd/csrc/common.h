@@ -1,0 +1,92 @@
+// Shared device/host helpers for libroma_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdint>
+#include "../../include/roma_hip.h"
+
+namespace roma {
+
+void set_error(const char* fmt, ...);
+
+#define ROMA_REQUIRE(cond, code, ...)            \
+  do {                                           \
+    if (!(cond)) {                               \
+      ::roma::set_error(__VA_ARGS__);            \
+      return (code);                             \
+    }                                            \
+  } while (0)
+
+#define ROMA_CHECK_LAUNCH()                                           \
+  do {                                                                \
+    hipError_t e_ = hipGetLastError();                                \
+    if (e_ != hipSuccess) {                                           \
+      ::roma::set_error("%s: %s", __func__, hipGetErrorString(e_));   \
+      return (int)e_;                                                 \
+    }                                                                 \
+    return 0;                                                         \
+  } while (0)
+
+typedef _Float16 half_t;
+typedef __bf16 bf16_t;
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf162_t __attribute__((ext_vector_type(2)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<float> { static constexpr int kPer16B = 4; };
+template <> struct ElemTraits<half_t> { static constexpr int kPer16B = 8; };
+template <> struct ElemTraits<bf16_t> { static constexpr int kPer16B = 8; };
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(half_t v) { return (float)v; }
+__device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ half_t from_f32<half_t>(float v) { return (half_t)v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+
+// dot of one 16-byte packet (4 f32 / 8 f16 / 8 bf16) accumulated in fp32
+template <typename T> __device__ __forceinline__ float dot16(const u32x4& a, const u32x4& b, float acc);
+template <> __device__ __forceinline__ float dot16<float>(const u32x4& a, const u32x4& b, float acc) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc = __builtin_fmaf(__uint_as_float(a[i]), __uint_as_float(b[i]), acc);
+  return acc;
+}
+template <> __device__ __forceinline__ float dot16<half_t>(const u32x4& a, const u32x4& b, float acc) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2_t, a[i]), __builtin_bit_cast(half2_t, b[i]), acc, false);
+  return acc;
+}
+template <> __device__ __forceinline__ float dot16<bf16_t>(const u32x4& a, const u32x4& b, float acc) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf162_t, a[i]), __builtin_bit_cast(bf162_t, b[i]), acc, false);
+  return acc;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// XCD-aware bijective remap of a linear block id: blocks that the dispatcher deals round-robin to one XCD get a
+// contiguous range of work items, so neighbouring tiles (which share halo rows) hit the same L2.  Speed only.
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+  const int q = nblocks >> 3, r = nblocks & 7, xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace roma

@@ -1,0 +1,84 @@
+// CosKernel on the CDNA4 matrix cores — reference: romatch/models/matcher.py:154-163 (used by GP.forward, :255-257).
+//   K[b,n,m] = exp((<x_n, y_m> / (|x_n| |y_m| + eps) - 1) / T)          x: (B,N,D), y: (B,M,D) fp32 row-major
+// This is the one dense C x C feature contraction of the path ("global correlation"), so it runs on MFMA.  The GP
+// is fp32 in the reference on every device (matcher.py:254), so the exact-fp32 form v_mfma_f32_32x32x2_f32 is used:
+// bit-for-bit an fmaf chain, 1/16 of the bf16 rate but still the full fp32 vector rate with the VALU left free.
+// 64x64 output tile per 256-thread workgroup (2x2 wavefronts of 32x32), K staged 16 deep through padded LDS tiles,
+// row/column norms accumulated from the same staged tiles, normalise + exp fused into the accumulator epilogue.
+#include "common.h"
+
+namespace roma {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int BT = 64, KT = 16, LD = KT + 1;
+
+__global__ __launch_bounds__(256) void cos_kernel_mfma(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ K,
+                                                       int N, int M, int D, float invT, float eps, float diag_add) {
+  __shared__ float sA[BT * LD], sB[BT * LD], sN[2 * BT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int b = blockIdx.z, n0 = blockIdx.y * BT, m0 = blockIdx.x * BT;
+  const float* xb = x + (size_t)b * N * D;
+  const float* yb = y + (size_t)b * M * D;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  float nrm = 0.f;                                   // threads 0..63: |x_row|^2, 64..127: |y_row|^2
+  const int lr = tid >> 2, lc = (tid & 3) * 4;       // loader: row 0..63, 4 consecutive k
+  for (int k0 = 0; k0 < D; k0 += KT) {
+    float4_t va{0, 0, 0, 0}, vb{0, 0, 0, 0};
+    if (n0 + lr < N) va = *reinterpret_cast<const float4_t*>(xb + (size_t)(n0 + lr) * D + k0 + lc);
+    if (m0 + lr < M) vb = *reinterpret_cast<const float4_t*>(yb + (size_t)(m0 + lr) * D + k0 + lc);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      sA[lr * LD + lc + i] = va[i];
+      sB[lr * LD + lc + i] = vb[i];
+    }
+    __syncthreads();
+    if (tid < 2 * BT) {
+      const float* r = (tid < BT ? sA : sB) + (tid & (BT - 1)) * LD;
+#pragma unroll
+      for (int i = 0; i < KT; ++i) nrm = __builtin_fmaf(r[i], r[i], nrm);
+    }
+    // lane l feeds A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31] of each 32x32x2 step
+    const float* pa = sA + (wr * 32 + (lane & 31)) * LD + (lane >> 5);
+    const float* pb = sB + (wc * 32 + (lane & 31)) * LD + (lane >> 5);
+#pragma unroll
+    for (int kk = 0; kk < KT; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[kk], pb[kk], acc, 0, 0, 0);
+  }
+  if (tid < 2 * BT) sN[tid] = sqrtf(nrm);
+  __syncthreads();
+  const int col = lane & 31;
+  const int m = m0 + wc * 32 + col;
+  const float ny = sN[BT + wc * 32 + col];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    const int n = n0 + wr * 32 + row;
+    if (n < N && m < M) {
+      const float c = acc[r] / (sN[wr * 32 + row] * ny + eps);
+      float v = expf((c - 1.f) * invT);
+      if (n == m) v += diag_add;
+      K[((size_t)b * N + n) * M + m] = v;
+    }
+  }
+}
+
+}  // namespace
+}  // namespace roma
+
+using namespace roma;
+
+extern "C" int roma_cos_kernel(const float* x, const float* y, float* K, int B, int N, int M, int D, float T, float eps,
+                               float diag_add, void* stream) {
+  ROMA_REQUIRE(x && y && K, ROMA_E_ARG, "roma_cos_kernel: null pointer");
+  ROMA_REQUIRE(B > 0 && N > 0 && M > 0 && D > 0, ROMA_E_SHAPE, "roma_cos_kernel: bad shape");
+  ROMA_REQUIRE(D % KT == 0, ROMA_E_SHAPE, "roma_cos_kernel: D=%d must be a multiple of %d", D, KT);
+  ROMA_REQUIRE(aligned16(x) && aligned16(y), ROMA_E_ALIGN, "roma_cos_kernel: x and y must be 16-byte aligned");
+  ROMA_REQUIRE(T > 0.f, ROMA_E_ARG, "roma_cos_kernel: temperature must be positive");
+  dim3 grid((M + BT - 1) / BT, (N + BT - 1) / BT, B);
+  hipLaunchKernelGGL(cos_kernel_mfma, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, y, K, N, M, D, 1.f / T, eps, diag_add);
+  ROMA_CHECK_LAUNCH();
+}

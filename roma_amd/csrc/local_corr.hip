@@ -1,0 +1,324 @@
+// local_correlation for gfx950 — reference: romatch/utils/local_correlation.py:4-48 (called at matcher.py:121-125).
+//
+// Formulation ("shared bilinear fraction"): the (2r+1)^2 window offsets are whole pixels, so every tap of
+// one pixel shares one bilinear fraction (ax, ay).  With (x0,y0) = floor of the un-normalised flow target,
+//     D[j][i] = <f0[:,y,x], f1[:, y0-r+j, x0-r+i]>      (0 <= i,j <= 2r+1, zero outside the image)
+//     corr[k=(iy,ix)] = C^-1/2 * ((1-ay)(1-ax) D[iy][ix] + (1-ay)ax D[iy][ix+1] + ay(1-ax) D[iy+1][ix] + ay ax D[iy+1][ix+1])
+// which never materialises the reference's (C,h,w,K) window tensor and needs (2r+2)^2 instead of 4(2r+1)^2 dot products.
+//
+// Mapping: one 256-thread workgroup owns a TW x TH tile of query pixels.  It computes the tile's bounding box of
+// target positions, stages that box of f1 (a CC-channel chunk at a time, channels-last rows) and the tile's f0 rows in
+// LDS, and every thread (pixel p, position group g) accumulates its NPOS dot products from LDS with packed dot2
+// (fp16/bf16) or fma (fp32), fp32 accumulation.  D is exchanged through LDS for the 4-tap blend and written out
+// coalesced.  Tiles whose bounding box does not fit in LDS (incoherent flow) read f1 rows straight from L2/HBM.
+#include "common.h"
+
+namespace roma {
+namespace {
+
+struct LCParams {
+  const void* f0;
+  const void* f1;
+  const float* flow;
+  void* out;
+  int B, C, H, W;
+  int f0_pitch, f1_pitch, out_pitch;
+  int in_nhwc, out_nhwc;
+  int tiles_x, tiles_y;
+  int max_rows;  // LDS capacity in f1 rows (excluding the zero row)
+  float scale;   // C^-1/2
+};
+
+template <int R> struct LCGeom;
+// TP pixels x PG position groups = 256 threads; NPOS = ceil((2R+2)^2 / PG) positions per thread
+template <> struct LCGeom<1> { static constexpr int TW = 8, TH = 8, PG = 4; };
+template <> struct LCGeom<2> { static constexpr int TW = 8, TH = 8, PG = 4; };
+template <> struct LCGeom<3> { static constexpr int TW = 8, TH = 8, PG = 4; };
+template <> struct LCGeom<4> { static constexpr int TW = 8, TH = 4, PG = 8; };
+template <> struct LCGeom<5> { static constexpr int TW = 8, TH = 4, PG = 8; };
+template <> struct LCGeom<6> { static constexpr int TW = 4, TH = 4, PG = 16; };
+template <> struct LCGeom<7> { static constexpr int TW = 4, TH = 4, PG = 16; };
+
+constexpr int kThreads = 256;
+
+// element address of (b, c, y, x) in a feature map
+__device__ __forceinline__ size_t feat_off(int nhwc, int b, int c, int y, int x, int pitch, int H, int W) {
+  return nhwc ? (((size_t)b * H + y) * W + x) * pitch + c : (((size_t)b * pitch + c) * H + y) * W + x;
+}
+
+template <typename T, int R, int CC>
+__global__ __launch_bounds__(kThreads) void local_corr_kernel(LCParams p) {
+  using G = LCGeom<R>;
+  constexpr int TW = G::TW, TH = G::TH, TP = TW * TH, PG = G::PG;
+  constexpr int N1 = 2 * R + 1, N2 = 2 * R + 2, Q = N2 * N2, K = N1 * N1;
+  constexpr int NPOS = (Q + PG - 1) / PG;
+  constexpr int E16 = ElemTraits<T>::kPer16B;     // elements per 16-byte packet
+  constexpr int PK = CC / E16;                    // packets per LDS row
+  constexpr int ROW16 = PK + 1;                   // row stride in packets (+1 packet pad: odd stride -> no bank conflicts)
+  static_assert(TP * PG == kThreads, "geometry");
+  static_assert(CC % E16 == 0, "chunk");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int* s_meta = reinterpret_cast<int*>(smem);                 // [0..3] bbox, [4] mode
+  int* s_x0 = s_meta + 8;
+  int* s_y0 = s_x0 + TP;
+  float* s_ax = reinterpret_cast<float*>(s_y0 + TP);
+  float* s_ay = s_ax + TP;
+  u32x4* s_f0 = reinterpret_cast<u32x4*>(s_ay + TP);          // TP rows
+  u32x4* s_f1 = s_f0 + TP * ROW16;                            // max_rows + 1 rows (last = zeros)
+  float* s_D = reinterpret_cast<float*>(s_f1);                // aliased after the channel loop: [TP][Q+1]
+
+  const int tid = threadIdx.x;
+  const int ntile = p.tiles_x * p.tiles_y;
+  const int wid = xcd_remap(blockIdx.x, gridDim.x);
+  const int b = wid / ntile;
+  const int t = wid - b * ntile;
+  const int ty0 = (t / p.tiles_x) * TH, tx0 = (t % p.tiles_x) * TW;
+  const int H = p.H, W = p.W;
+
+  if (tid < 4) s_meta[tid] = (tid < 2) ? 0x7fffffff : -0x7fffffff;
+  __syncthreads();
+  if (tid < TP) {
+    const int y = ty0 + tid / TW, x = tx0 + tid % TW;
+    int x0 = 0, y0 = 0;
+    float ax = 0.f, ay = 0.f;
+    const bool valid = (y < H) && (x < W);
+    if (valid) {
+      float fx, fy;
+      if (p.flow) {
+        fx = p.flow[((size_t)(b * 2 + 0) * H + y) * W + x];
+        fy = p.flow[((size_t)(b * 2 + 1) * H + y) * W + x];
+      } else {
+        fx = -1.f + (2.f * x + 1.f) / W;
+        fy = -1.f + (2.f * y + 1.f) / H;
+      }
+      float px = ((fx + 1.f) * W - 1.f) * 0.5f, py = ((fy + 1.f) * H - 1.f) * 0.5f;
+      // keep the integer conversion defined for wild / non-finite flow: such targets are fully outside the image
+      if (!(px > -1e6f && px < 1e6f)) px = -1e6f;
+      if (!(py > -1e6f && py < 1e6f)) py = -1e6f;
+      const float fx0 = floorf(px), fy0 = floorf(py);
+      ax = px - fx0;
+      ay = py - fy0;
+      x0 = (int)fx0;
+      y0 = (int)fy0;
+      const int lox = max(x0 - R, 0), hix = min(x0 + R + 1, W - 1);
+      const int loy = max(y0 - R, 0), hiy = min(y0 + R + 1, H - 1);
+      if (lox <= hix && loy <= hiy) {
+        atomicMin(&s_meta[0], lox);
+        atomicMin(&s_meta[1], loy);
+        atomicMax(&s_meta[2], hix);
+        atomicMax(&s_meta[3], hiy);
+      }
+    }
+    s_x0[tid] = x0;
+    s_y0[tid] = y0;
+    s_ax[tid] = ax;
+    s_ay[tid] = ay;
+  }
+  __syncthreads();
+  const int bx0 = s_meta[0], by0 = s_meta[1];
+  int bw = s_meta[2] - bx0 + 1, bh = s_meta[3] - by0 + 1;
+  if (bw < 0 || bh < 0) bw = bh = 0;                           // every window is outside the image
+  const int nrows = bw * bh;
+  const bool staged = nrows <= p.max_rows;                     // else: read f1 rows from global memory directly
+  const int zero_row = staged ? nrows : 0;
+
+  // per-thread work list: pixel pp, positions q = g*NPOS .. g*NPOS+NPOS-1
+  const int pp = tid % TP, g = tid / TP;
+  const int my_x0 = s_x0[pp], my_y0 = s_y0[pp];
+  const int py_img = ty0 + pp / TW, px_img = tx0 + pp % TW;
+  const bool pvalid = (py_img < H) && (px_img < W);
+  int rowoff[NPOS];      // staged: LDS row index; direct: pixel index y*W+x (or -1)
+#pragma unroll
+  for (int i = 0; i < NPOS; ++i) {
+    const int q = g * NPOS + i;
+    const int yy = my_y0 - R + q / N2, xx = my_x0 - R + q % N2;
+    const bool ok = pvalid && (q < Q) && (yy >= 0) && (yy < H) && (xx >= 0) && (xx < W);
+    rowoff[i] = staged ? (ok ? (yy - by0) * bw + (xx - bx0) : zero_row) : (ok ? yy * W + xx : -1);
+  }
+  float acc[NPOS];
+#pragma unroll
+  for (int i = 0; i < NPOS; ++i) acc[i] = 0.f;
+
+  const T* f0 = static_cast<const T*>(p.f0);
+  const T* f1 = static_cast<const T*>(p.f1);
+  if (staged) {                                                // zero row
+    for (int i = tid; i < ROW16; i += kThreads) s_f1[zero_row * ROW16 + i] = u32x4{0, 0, 0, 0};
+  }
+
+  for (int c0 = 0; c0 < p.C; c0 += CC) {
+    // ---- stage f0 tile rows and the f1 bounding box (channels c0..c0+CC) ----
+    if (p.in_nhwc) {
+      for (int i = tid; i < TP * PK; i += kThreads) {
+        const int row = i / PK, k = i - row * PK;
+        const int y = ty0 + row / TW, x = tx0 + row % TW;
+        u32x4 v{0, 0, 0, 0};
+        if (y < H && x < W && c0 + k * E16 < p.C)
+          v = *reinterpret_cast<const u32x4*>(f0 + feat_off(1, b, c0 + k * E16, y, x, p.f0_pitch, H, W));
+        s_f0[row * ROW16 + k] = v;
+      }
+      if (staged) {
+        for (int i = tid; i < nrows * PK; i += kThreads) {
+          const int row = i / PK, k = i - row * PK;
+          const int y = by0 + row / bw, x = bx0 + row % bw;
+          u32x4 v{0, 0, 0, 0};
+          if (c0 + k * E16 < p.C)
+            v = *reinterpret_cast<const u32x4*>(f1 + feat_off(1, b, c0 + k * E16, y, x, p.f1_pitch, H, W));
+          s_f1[row * ROW16 + k] = v;
+        }
+      }
+    } else {
+      // planar input: lanes run along x (contiguous), LDS write transposes to channels-last rows
+      T* s0 = reinterpret_cast<T*>(s_f0);
+      for (int i = tid; i < TP * CC; i += kThreads) {
+        const int c = i / TP, row = i - c * TP;
+        const int y = ty0 + row / TW, x = tx0 + row % TW;
+        T v = from_f32<T>(0.f);
+        if (y < H && x < W && c0 + c < p.C) v = f0[feat_off(0, b, c0 + c, y, x, p.f0_pitch, H, W)];
+        s0[row * ROW16 * E16 + c] = v;
+      }
+      if (staged) {
+        T* s1 = reinterpret_cast<T*>(s_f1);
+        for (int i = tid; i < nrows * CC; i += kThreads) {
+          const int c = i / nrows, row = i - c * nrows;
+          const int y = by0 + row / bw, x = bx0 + row % bw;
+          T v = from_f32<T>(0.f);
+          if (c0 + c < p.C) v = f1[feat_off(0, b, c0 + c, y, x, p.f1_pitch, H, W)];
+          s1[row * ROW16 * E16 + c] = v;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- dot products ----
+    u32x4 a[PK];
+#pragma unroll
+    for (int k = 0; k < PK; ++k) a[k] = s_f0[pp * ROW16 + k];
+    if (staged) {
+#pragma unroll
+      for (int i = 0; i < NPOS; ++i) {
+        const u32x4* row = s_f1 + rowoff[i] * ROW16;
+        float s = acc[i];
+#pragma unroll
+        for (int k = 0; k < PK; ++k) s = dot16<T>(a[k], row[k], s);
+        acc[i] = s;
+      }
+    } else {
+      // incoherent tile: f1 rows come straight from L2/HBM (correct for any flow, not the fast path)
+      const T* a_el = reinterpret_cast<const T*>(s_f0 + pp * ROW16);
+#pragma unroll
+      for (int i = 0; i < NPOS; ++i) {
+        if (rowoff[i] >= 0) {
+          const int yy = rowoff[i] / W, xx = rowoff[i] - yy * W;
+          float s = acc[i];
+          if (p.in_nhwc) {
+            const T* src = f1 + feat_off(1, b, c0, yy, xx, p.f1_pitch, H, W);
+#pragma unroll 1
+            for (int k = 0; k < PK; ++k)
+              if (c0 + k * E16 < p.C)
+                s = dot16<T>(s_f0[pp * ROW16 + k], *reinterpret_cast<const u32x4*>(src + k * E16), s);
+          } else {
+#pragma unroll 1
+            for (int c = 0; c < CC && c0 + c < p.C; ++c)
+              s = __builtin_fmaf(to_f32(a_el[c]), to_f32(f1[feat_off(0, b, c0 + c, yy, xx, p.f1_pitch, H, W)]), s);
+          }
+          acc[i] = s;
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- exchange D through LDS, blend, write ----
+#pragma unroll
+  for (int i = 0; i < NPOS; ++i) {
+    const int q = g * NPOS + i;
+    if (q < Q) s_D[pp * (Q + 1) + q] = acc[i] * p.scale;
+  }
+  __syncthreads();
+  T* out = static_cast<T*>(p.out);
+  for (int e = tid; e < TP * K; e += kThreads) {
+    int pix, k;
+    if (p.out_nhwc) { pix = e / K; k = e - pix * K; } else { k = e / TP; pix = e - k * TP; }
+    const int y = ty0 + pix / TW, x = tx0 + pix % TW;
+    if (y >= H || x >= W) continue;
+    const int iy = k / N1, ix = k - iy * N1;
+    const float ax = s_ax[pix], ay = s_ay[pix];
+    const float* d = s_D + pix * (Q + 1) + iy * N2 + ix;
+    const float top = d[0] + ax * (d[1] - d[0]);
+    const float bot = d[N2] + ax * (d[N2 + 1] - d[N2]);
+    const float v = top + ay * (bot - top);
+    out[feat_off(p.out_nhwc, b, k, y, x, p.out_pitch, H, W)] = from_f32<T>(v);
+  }
+}
+
+template <typename T, int R>
+int launch_lc(LCParams p, hipStream_t stream) {
+  using G = LCGeom<R>;
+  constexpr int CC = 64 * 2 / sizeof(T) >= 64 ? 64 : 32;      // 128-byte LDS rows: 64 halves / 32 floats
+  constexpr int TP = G::TW * G::TH, Q = (2 * R + 2) * (2 * R + 2);
+  constexpr int ROWB = (CC / ElemTraits<T>::kPer16B + 1) * 16;
+  p.tiles_x = (p.W + G::TW - 1) / G::TW;
+  p.tiles_y = (p.H + G::TH - 1) / G::TH;
+  // LDS budget: about 60 KiB per workgroup so that two workgroups share a CU
+  const int meta = (8 + 2 * TP) * 4 + 2 * TP * 4;
+  const int budget = 60 * 1024;
+  p.max_rows = (budget - meta - TP * ROWB) / ROWB - 1;
+  const int need_D = TP * (Q + 1) * 4;
+  size_t smem = (size_t)meta + (size_t)TP * ROWB + (size_t)(p.max_rows + 1) * ROWB;
+  if (smem < (size_t)meta + (size_t)TP * ROWB + need_D) smem = (size_t)meta + (size_t)TP * ROWB + need_D;
+  const int grid = p.B * p.tiles_x * p.tiles_y;
+  hipLaunchKernelGGL((local_corr_kernel<T, R, CC>), dim3(grid), dim3(kThreads), smem, stream, p);
+  ROMA_CHECK_LAUNCH();
+}
+
+template <typename T>
+int dispatch_r(const LCParams& p, int r, hipStream_t s) {
+  switch (r) {
+    case 1: return launch_lc<T, 1>(p, s);
+    case 2: return launch_lc<T, 2>(p, s);
+    case 3: return launch_lc<T, 3>(p, s);
+    case 4: return launch_lc<T, 4>(p, s);
+    case 5: return launch_lc<T, 5>(p, s);
+    case 6: return launch_lc<T, 6>(p, s);
+    case 7: return launch_lc<T, 7>(p, s);
+  }
+  set_error("roma_local_corr: radius %d outside 1..7", r);
+  return ROMA_E_UNSUPPORTED;
+}
+
+}  // namespace
+}  // namespace roma
+
+extern "C" int roma_local_corr(const void* f0, const void* f1, const float* flow, void* out, int B, int C, int H, int W,
+                               int r, int dtype, int layout, int f0_pitch, int f1_pitch, int out_layout, int out_pitch,
+                               void* stream) {
+  using namespace roma;
+  ROMA_REQUIRE(f0 && f1 && out, ROMA_E_ARG, "roma_local_corr: null pointer");
+  ROMA_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, ROMA_E_SHAPE, "roma_local_corr: bad shape B=%d C=%d H=%d W=%d", B, C, H, W);
+  ROMA_REQUIRE(r >= 1 && r <= 7, ROMA_E_UNSUPPORTED, "roma_local_corr: radius %d outside 1..7", r);
+  ROMA_REQUIRE(layout == ROMA_NCHW || layout == ROMA_NHWC, ROMA_E_ARG, "roma_local_corr: bad layout %d", layout);
+  ROMA_REQUIRE(out_layout == ROMA_NCHW || out_layout == ROMA_NHWC, ROMA_E_ARG, "roma_local_corr: bad out_layout %d", out_layout);
+  const int K = (2 * r + 1) * (2 * r + 1);
+  ROMA_REQUIRE(f0_pitch >= C && f1_pitch >= C && out_pitch >= K, ROMA_E_SHAPE, "roma_local_corr: pitch smaller than channel count");
+  const int esz = dtype == ROMA_F32 ? 4 : 2;
+  if (layout == ROMA_NHWC) {
+    const int e16 = 16 / esz;
+    ROMA_REQUIRE(C % e16 == 0 && f0_pitch % e16 == 0 && f1_pitch % e16 == 0 && aligned16(f0) && aligned16(f1), ROMA_E_ALIGN,
+                 "roma_local_corr: channels-last inputs need C and pitches multiples of %d and 16-byte aligned bases", e16);
+  }
+  ROMA_REQUIRE((size_t)B * H * W * (size_t)(f0_pitch > out_pitch ? f0_pitch : out_pitch) < (1ull << 40), ROMA_E_SHAPE, "roma_local_corr: tensor too large");
+  LCParams p{};
+  p.f0 = f0; p.f1 = f1; p.flow = flow; p.out = out;
+  p.B = B; p.C = C; p.H = H; p.W = W;
+  p.f0_pitch = f0_pitch; p.f1_pitch = f1_pitch; p.out_pitch = out_pitch;
+  p.in_nhwc = layout == ROMA_NHWC; p.out_nhwc = out_layout == ROMA_NHWC;
+  p.scale = 1.0f / sqrtf((float)C);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (dtype) {
+    case ROMA_F32: return dispatch_r<float>(p, r, s);
+    case ROMA_F16: return dispatch_r<half_t>(p, r, s);
+    case ROMA_BF16: return dispatch_r<bf16_t>(p, r, s);
+  }
+  set_error("roma_local_corr: unknown dtype %d", dtype);
+  return ROMA_E_DTYPE;
+}

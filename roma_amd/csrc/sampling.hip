@@ -1,0 +1,301 @@
+// Bilinear sampling family for gfx950: grid_sample warp, planar bilinear resize, displacement embedding, flow update.
+// References: matcher.py:109 (F.grid_sample in ConvRefiner.forward), matcher.py:349-360,408-417,657-659 (F.interpolate),
+// matcher.py:111-120 (disp_emb), matcher.py:397-402 (flow / certainty update).
+// All of these are HBM-bound elementwise/gather kernels: 16-byte packets along the channel axis of channels-last
+// features, fp32 arithmetic, one pass.
+#include "common.h"
+
+namespace roma {
+namespace {
+
+// torch.linspace(-1+1/n, 1-1/n, n)[i], evaluated the way ATen does (symmetric around the midpoint)
+__device__ __forceinline__ float pix_center(int i, int n) {
+  const float start = -1.f + 1.f / n, end = 1.f - 1.f / n;
+  if (n == 1) return start;
+  const float step = (end - start) / (float)(n - 1);
+  return (i < n / 2) ? start + step * i : end - step * (n - 1 - i);
+}
+
+template <typename T> __device__ __forceinline__ void unpack16(const u32x4& v, float* f);
+template <> __device__ __forceinline__ void unpack16<float>(const u32x4& v, float* f) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) f[i] = __uint_as_float(v[i]);
+}
+template <> __device__ __forceinline__ void unpack16<half_t>(const u32x4& v, float* f) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const half2_t h = __builtin_bit_cast(half2_t, v[i]);
+    f[2 * i] = (float)h[0];
+    f[2 * i + 1] = (float)h[1];
+  }
+}
+template <> __device__ __forceinline__ void unpack16<bf16_t>(const u32x4& v, float* f) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = __uint_as_float(v[i] << 16);
+    f[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
+  }
+}
+template <typename T> __device__ __forceinline__ u32x4 pack16(const float* f);
+template <> __device__ __forceinline__ u32x4 pack16<float>(const float* f) {
+  return u32x4{__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3])};
+}
+template <> __device__ __forceinline__ u32x4 pack16<half_t>(const float* f) {
+  u32x4 v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    half2_t h{(half_t)f[2 * i], (half_t)f[2 * i + 1]};
+    v[i] = __builtin_bit_cast(uint32_t, h);
+  }
+  return v;
+}
+template <> __device__ __forceinline__ u32x4 pack16<bf16_t>(const float* f) {
+  u32x4 v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    bf162_t h{(bf16_t)f[2 * i], (bf16_t)f[2 * i + 1]};
+    v[i] = __builtin_bit_cast(uint32_t, h);
+  }
+  return v;
+}
+
+struct Corner {
+  int x0, y0;
+  float w00, w01, w10, w11;  // wYX
+  bool v00, v01, v10, v11;
+};
+
+__device__ __forceinline__ Corner corners(float fx, float fy, int Hs, int Ws) {
+  float px = ((fx + 1.f) * Ws - 1.f) * 0.5f, py = ((fy + 1.f) * Hs - 1.f) * 0.5f;
+  if (!(px > -1e6f && px < 1e6f)) px = -1e6f;
+  if (!(py > -1e6f && py < 1e6f)) py = -1e6f;
+  const float fx0 = floorf(px), fy0 = floorf(py);
+  const float ax = px - fx0, ay = py - fy0;
+  Corner c;
+  c.x0 = (int)fx0;
+  c.y0 = (int)fy0;
+  c.w00 = (1.f - ay) * (1.f - ax);
+  c.w01 = (1.f - ay) * ax;
+  c.w10 = ay * (1.f - ax);
+  c.w11 = ay * ax;
+  const bool xa = c.x0 >= 0 && c.x0 < Ws, xb = c.x0 + 1 >= 0 && c.x0 + 1 < Ws;
+  const bool ya = c.y0 >= 0 && c.y0 < Hs, yb = c.y0 + 1 >= 0 && c.y0 + 1 < Hs;
+  c.v00 = ya && xa;
+  c.v01 = ya && xb;
+  c.v10 = yb && xa;
+  c.v11 = yb && xb;
+  return c;
+}
+
+// channels-last source and destination, C a multiple of the packet width
+template <typename T>
+__global__ __launch_bounds__(256) void warp_nhwc_kernel(const T* __restrict__ src, const float* __restrict__ flow,
+                                                        T* __restrict__ dst, int B, int C, int Hs, int Ws, int H, int W,
+                                                        int src_pitch, int dst_pitch) {
+  constexpr int E16 = ElemTraits<T>::kPer16B;
+  const int PK = C / E16;
+  const size_t total = (size_t)B * H * W * PK;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i % PK);
+    const size_t pix = i / PK;
+    const int x = (int)(pix % W);
+    const int y = (int)((pix / W) % H);
+    const int b = (int)(pix / ((size_t)W * H));
+    const float fx = flow[((size_t)(b * 2 + 0) * H + y) * W + x];
+    const float fy = flow[((size_t)(b * 2 + 1) * H + y) * W + x];
+    const Corner c = corners(fx, fy, Hs, Ws);
+    float acc[E16];
+#pragma unroll
+    for (int e = 0; e < E16; ++e) acc[e] = 0.f;
+    const T* base = src + (size_t)b * Hs * Ws * src_pitch + (size_t)k * E16;
+    auto tap = [&](bool ok, int yy, int xx, float w) {
+      if (ok) {
+        float f[E16];
+        unpack16<T>(*reinterpret_cast<const u32x4*>(base + ((size_t)yy * Ws + xx) * src_pitch), f);
+#pragma unroll
+        for (int e = 0; e < E16; ++e) acc[e] = __builtin_fmaf(w, f[e], acc[e]);
+      }
+    };
+    tap(c.v00, c.y0, c.x0, c.w00);
+    tap(c.v01, c.y0, c.x0 + 1, c.w01);
+    tap(c.v10, c.y0 + 1, c.x0, c.w10);
+    tap(c.v11, c.y0 + 1, c.x0 + 1, c.w11);
+    *reinterpret_cast<u32x4*>(dst + pix * dst_pitch + (size_t)k * E16) = pack16<T>(acc);
+  }
+}
+
+// any layout combination, scalar accesses; x runs fastest over lanes for planar data, c for channels-last
+template <typename T>
+__global__ __launch_bounds__(256) void warp_generic_kernel(const T* __restrict__ src, const float* __restrict__ flow,
+                                                           T* __restrict__ dst, int B, int C, int Hs, int Ws, int H, int W,
+                                                           int src_nhwc, int src_pitch, int dst_nhwc, int dst_pitch) {
+  const size_t total = (size_t)B * C * H * W;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    int b, ch, y, x;
+    if (dst_nhwc) {
+      ch = (int)(i % C);
+      size_t r = i / C;
+      x = (int)(r % W); r /= W;
+      y = (int)(r % H);
+      b = (int)(r / H);
+    } else {
+      x = (int)(i % W);
+      size_t r = i / W;
+      y = (int)(r % H); r /= H;
+      ch = (int)(r % C);
+      b = (int)(r / C);
+    }
+    const float fx = flow[((size_t)(b * 2 + 0) * H + y) * W + x];
+    const float fy = flow[((size_t)(b * 2 + 1) * H + y) * W + x];
+    const Corner c = corners(fx, fy, Hs, Ws);
+    auto at = [&](int yy, int xx) -> float {
+      const size_t o = src_nhwc ? (((size_t)b * Hs + yy) * Ws + xx) * src_pitch + ch
+                                : (((size_t)b * src_pitch + ch) * Hs + yy) * Ws + xx;
+      return to_f32(src[o]);
+    };
+    float v = 0.f;
+    if (c.v00) v = __builtin_fmaf(c.w00, at(c.y0, c.x0), v);
+    if (c.v01) v = __builtin_fmaf(c.w01, at(c.y0, c.x0 + 1), v);
+    if (c.v10) v = __builtin_fmaf(c.w10, at(c.y0 + 1, c.x0), v);
+    if (c.v11) v = __builtin_fmaf(c.w11, at(c.y0 + 1, c.x0 + 1), v);
+    const size_t o = dst_nhwc ? (((size_t)b * H + y) * W + x) * dst_pitch + ch : (((size_t)b * dst_pitch + ch) * H + y) * W + x;
+    dst[o] = from_f32<T>(v);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void disp_emb_kernel(const float* __restrict__ flow, const float* __restrict__ weight,
+                                                       const float* __restrict__ bias, T* __restrict__ dst, int B, int E, int H,
+                                                       int W, float gain, int dst_nhwc, int dst_pitch) {
+  const size_t total = (size_t)B * E * H * W;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    int b, e, y, x;
+    if (dst_nhwc) {
+      e = (int)(i % E);
+      size_t r = i / E;
+      x = (int)(r % W); r /= W;
+      y = (int)(r % H);
+      b = (int)(r / H);
+    } else {
+      x = (int)(i % W);
+      size_t r = i / W;
+      y = (int)(r % H); r /= H;
+      e = (int)(r % E);
+      b = (int)(r / E);
+    }
+    const float dx = gain * (flow[((size_t)(b * 2 + 0) * H + y) * W + x] - pix_center(x, W));
+    const float dy = gain * (flow[((size_t)(b * 2 + 1) * H + y) * W + x] - pix_center(y, H));
+    const float v = __builtin_fmaf(weight[2 * e + 1], dy, __builtin_fmaf(weight[2 * e], dx, bias[e]));
+    const size_t o = dst_nhwc ? (((size_t)b * H + y) * W + x) * dst_pitch + e : (((size_t)b * dst_pitch + e) * H + y) * W + x;
+    dst[o] = from_f32<T>(v);
+  }
+}
+
+// ATen upsample_bilinear2d, align_corners=False: src = max((dst+0.5)*in/out-0.5, 0)
+__device__ __forceinline__ void interp_src(int d, int in, int out, int& i0, int& i1, float& l1) {
+  const float scale = (float)in / (float)out;
+  float s = scale * (d + 0.5f) - 0.5f;
+  s = s < 0.f ? 0.f : s;
+  i0 = (int)s;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  l1 = s - (float)i0;
+}
+
+__global__ __launch_bounds__(256) void interp_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int Hi, int Wi,
+                                                     int Ho, int Wo) {
+  const size_t total = (size_t)N * Ho * Wo;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int xo = (int)(i % Wo);
+    const int yo = (int)((i / Wo) % Ho);
+    const int n = (int)(i / ((size_t)Wo * Ho));
+    int y0, y1, x0, x1;
+    float ly, lx;
+    interp_src(yo, Hi, Ho, y0, y1, ly);
+    interp_src(xo, Wi, Wo, x0, x1, lx);
+    const float* p = x + (size_t)n * Hi * Wi;
+    const float top = (1.f - lx) * p[(size_t)y0 * Wi + x0] + lx * p[(size_t)y0 * Wi + x1];
+    const float bot = (1.f - lx) * p[(size_t)y1 * Wi + x0] + lx * p[(size_t)y1 * Wi + x1];
+    y[i] = (1.f - ly) * top + ly * bot;
+  }
+}
+
+__global__ __launch_bounds__(256) void flow_update_kernel(float* __restrict__ flow, float* __restrict__ cert,
+                                                          const float* __restrict__ cert_in, const float* __restrict__ delta, int B,
+                                                          int HW, float sx, float sy) {
+  const size_t total = (size_t)B * HW;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / HW);
+    const int p = (int)(i - (size_t)b * HW);
+    const float* d = delta + (size_t)b * 3 * HW + p;
+    float* f = flow + (size_t)b * 2 * HW + p;
+    f[0] += sx * d[0];
+    f[HW] += sy * d[HW];
+    cert[i] = (cert_in ? cert_in[i] : 0.f) + d[2 * (size_t)HW];
+  }
+}
+
+inline int grid_for(size_t total) {
+  size_t g = (total + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+}  // namespace
+}  // namespace roma
+
+using namespace roma;
+
+extern "C" int roma_warp_bilinear(const void* src, const float* flow, void* dst, int B, int C, int Hs, int Ws, int H, int W,
+                                  int dtype, int layout, int src_pitch, int dst_layout, int dst_pitch, void* stream) {
+  ROMA_REQUIRE(src && flow && dst, ROMA_E_ARG, "roma_warp_bilinear: null pointer");
+  ROMA_REQUIRE(B > 0 && C > 0 && Hs > 0 && Ws > 0 && H > 0 && W > 0, ROMA_E_SHAPE, "roma_warp_bilinear: bad shape");
+  ROMA_REQUIRE(src_pitch >= C && dst_pitch >= C, ROMA_E_SHAPE, "roma_warp_bilinear: pitch smaller than channel count");
+  ROMA_REQUIRE(dtype >= ROMA_F32 && dtype <= ROMA_BF16, ROMA_E_DTYPE, "roma_warp_bilinear: unknown dtype %d", dtype);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int e16 = dtype == ROMA_F32 ? 4 : 8;
+  const bool vec = layout == ROMA_NHWC && dst_layout == ROMA_NHWC && C % e16 == 0 && src_pitch % e16 == 0 &&
+                   dst_pitch % e16 == 0 && aligned16(src) && aligned16(dst);
+  const size_t total = vec ? (size_t)B * H * W * (C / e16) : (size_t)B * H * W * C;
+#define ROMA_WARP(T)                                                                                                     \
+  if (vec)                                                                                                               \
+    hipLaunchKernelGGL((warp_nhwc_kernel<T>), dim3(grid_for(total)), dim3(256), 0, s, (const T*)src, flow, (T*)dst, B, C, Hs, \
+                       Ws, H, W, src_pitch, dst_pitch);                                                                  \
+  else                                                                                                                   \
+    hipLaunchKernelGGL((warp_generic_kernel<T>), dim3(grid_for(total)), dim3(256), 0, s, (const T*)src, flow, (T*)dst, B, C, \
+                       Hs, Ws, H, W, layout == ROMA_NHWC, src_pitch, dst_layout == ROMA_NHWC, dst_pitch);
+  if (dtype == ROMA_F32) { ROMA_WARP(float) } else if (dtype == ROMA_F16) { ROMA_WARP(half_t) } else { ROMA_WARP(bf16_t) }
+#undef ROMA_WARP
+  ROMA_CHECK_LAUNCH();
+}
+
+extern "C" int roma_disp_emb(const float* flow, const float* weight, const float* bias, void* dst, int B, int E, int H, int W,
+                             float gain, int dtype, int dst_layout, int dst_pitch, void* stream) {
+  ROMA_REQUIRE(flow && weight && bias && dst, ROMA_E_ARG, "roma_disp_emb: null pointer");
+  ROMA_REQUIRE(B > 0 && E > 0 && H > 0 && W > 0 && dst_pitch >= E, ROMA_E_SHAPE, "roma_disp_emb: bad shape");
+  ROMA_REQUIRE(dtype >= ROMA_F32 && dtype <= ROMA_BF16, ROMA_E_DTYPE, "roma_disp_emb: unknown dtype %d", dtype);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t total = (size_t)B * E * H * W;
+  const int nhwc = dst_layout == ROMA_NHWC;
+  if (dtype == ROMA_F32)
+    hipLaunchKernelGGL((disp_emb_kernel<float>), dim3(grid_for(total)), dim3(256), 0, s, flow, weight, bias, (float*)dst, B, E, H, W, gain, nhwc, dst_pitch);
+  else if (dtype == ROMA_F16)
+    hipLaunchKernelGGL((disp_emb_kernel<half_t>), dim3(grid_for(total)), dim3(256), 0, s, flow, weight, bias, (half_t*)dst, B, E, H, W, gain, nhwc, dst_pitch);
+  else
+    hipLaunchKernelGGL((disp_emb_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, s, flow, weight, bias, (bf16_t*)dst, B, E, H, W, gain, nhwc, dst_pitch);
+  ROMA_CHECK_LAUNCH();
+}
+
+extern "C" int roma_interp_bilinear(const float* x, float* y, int N, int Hi, int Wi, int Ho, int Wo, void* stream) {
+  ROMA_REQUIRE(x && y, ROMA_E_ARG, "roma_interp_bilinear: null pointer");
+  ROMA_REQUIRE(N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, ROMA_E_SHAPE, "roma_interp_bilinear: bad shape");
+  hipLaunchKernelGGL(interp_kernel, dim3(grid_for((size_t)N * Ho * Wo)), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, N, Hi, Wi, Ho, Wo);
+  ROMA_CHECK_LAUNCH();
+}
+
+extern "C" int roma_flow_update(float* flow, float* cert, const float* cert_in, const float* delta, int B, int H, int W, float sx,
+                                float sy, void* stream) {
+  ROMA_REQUIRE(flow && cert && delta, ROMA_E_ARG, "roma_flow_update: null pointer");
+  ROMA_REQUIRE(B > 0 && H > 0 && W > 0, ROMA_E_SHAPE, "roma_flow_update: bad shape");
+  hipLaunchKernelGGL(flow_update_kernel, dim3(grid_for((size_t)B * H * W)), dim3(256), 0, static_cast<hipStream_t>(stream), flow, cert, cert_in, delta, B, H * W, sx, sy);
+  ROMA_CHECK_LAUNCH();
+}

@@ -1,0 +1,253 @@
+"""Operator-level seams of the reference, backed by the gfx950 kernels in libroma_hip.so.
+
+Same names, arguments and error behaviour as the reference's module-level functions
+(`local_correlation` romatch/utils/local_correlation.py:4, `cls_to_flow_refine` romatch/utils/utils.py:301,
+`kde` romatch/utils/kde.py:4), plus the lower-level helpers the matcher uses.  Tensors must live on a ROCm
+device; anything else raises — there is no CPU or eager-PyTorch fallback here by design.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import ROMA_BF16, ROMA_F16, ROMA_F32, ROMA_NCHW, ROMA_NHWC, check
+
+_DT = {torch.float32: ROMA_F32, torch.float16: ROMA_F16, torch.bfloat16: ROMA_BF16}
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("roma_amd kernels run on an MI355X (ROCm device tensors) only; got a "
+                               f"{t.device} tensor and there is no CPU fallback")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dt(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise ValueError(f"unsupported dtype {t.dtype}") from None
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def feat_layout(t: torch.Tensor):
+    """(layout, pitch, tensor) of a (B,C,H,W) feature map: channels-last storage (possibly a channel slice of a wider
+    channels-last buffer) -> NHWC, contiguous -> NCHW, anything else is made contiguous."""
+    B, C, H, W = t.shape
+    sb, sc, sh, sw = t.stride()
+    if sc == 1 and sh == W * sw and sb == H * W * sw and sw >= C:
+        return ROMA_NHWC, sw, t
+    if t.is_contiguous():
+        return ROMA_NCHW, C, t
+    t = t.contiguous()
+    return ROMA_NCHW, C, t
+
+
+def nhwc_empty(B, C, H, W, dtype, device, pitch=None):
+    """A (B,C,H,W)-shaped view of fresh channels-last storage with `pitch` >= C channels per pixel."""
+    pitch = pitch or C
+    buf = torch.empty((B, H, W, pitch), dtype=dtype, device=device)
+    return buf[..., :C].permute(0, 3, 1, 2)
+
+
+def local_correlation(feature0, feature1, local_radius, padding_mode="zeros", flow=None, sample_mode="bilinear", out=None):
+    """romatch/utils/local_correlation.py:4-48.  Returns (B,(2r+1)^2,h,w) in feature0's dtype and memory format
+    (or fills `out`, e.g. a channel slice of the refiner's channels-last concat buffer)."""
+    if padding_mode != "zeros" or sample_mode != "bilinear":
+        raise NotImplementedError("only padding_mode='zeros', sample_mode='bilinear' (the modes RoMa uses)")
+    _need_gpu(feature0, feature1, flow, out)
+    if feature0.shape != feature1.shape or feature0.dtype != feature1.dtype:
+        raise ValueError("feature0/feature1 must have the same shape and dtype")
+    B, C, H, W = feature0.shape
+    r = int(local_radius)
+    K = (2 * r + 1) ** 2
+    l0, p0, f0 = feat_layout(feature0)
+    l1, p1, f1 = feat_layout(feature1)
+    if l0 != l1:                                   # one layout per call: bring f1 to f0's
+        f1 = f1.contiguous(memory_format=torch.channels_last if l0 == ROMA_NHWC else torch.contiguous_format)
+        l1, p1, f1 = feat_layout(f1)
+    if flow is not None:
+        if tuple(flow.shape) != (B, 2, H, W):
+            raise ValueError(f"flow must be (B,2,h,w), got {tuple(flow.shape)}")
+        flow = flow.float().contiguous()
+    if out is None:
+        out = nhwc_empty(B, K, H, W, feature0.dtype, feature0.device) if l0 == ROMA_NHWC else \
+            torch.empty((B, K, H, W), dtype=feature0.dtype, device=feature0.device)
+    lo, po, o = feat_layout(out)
+    if o is not out or tuple(out.shape) != (B, K, H, W) or out.dtype != feature0.dtype:
+        raise ValueError("out must be a (B,K,h,w) tensor of the input dtype, contiguous or channels-last")
+    check(_lib.load().roma_local_corr(_p(f0), _p(f1), _p(flow), _p(out), B, C, H, W, r, _dt(f0), l0, p0, p1, lo, po, _stream()),
+          "roma_local_corr")
+    return out
+
+
+def warp_bilinear(src, flow, out=None):
+    """F.grid_sample(src, flow.permute(0,2,3,1), mode='bilinear', align_corners=False) — matcher.py:109."""
+    _need_gpu(src, flow, out)
+    B, C, Hs, Ws = src.shape
+    _, _, H, W = flow.shape
+    ls, ps, s = feat_layout(src)
+    flow = flow.float().contiguous()
+    if out is None:
+        out = nhwc_empty(B, C, H, W, src.dtype, src.device) if ls == ROMA_NHWC else torch.empty((B, C, H, W), dtype=src.dtype, device=src.device)
+    lo, po, o = feat_layout(out)
+    if o is not out:
+        raise ValueError("out must be contiguous or channels-last")
+    check(_lib.load().roma_warp_bilinear(_p(s), _p(flow), _p(out), B, C, Hs, Ws, H, W, _dt(s), ls, ps, lo, po, _stream()),
+          "roma_warp_bilinear")
+    return out
+
+
+def disp_emb(flow, weight, bias, gain, out=None, dtype=torch.float32):
+    """Conv1x1(2->E)(gain*(flow - identity_grid)) — matcher.py:111-120.  weight (E,2[,1,1]), bias (E)."""
+    _need_gpu(flow, weight, bias, out)
+    B, _, H, W = flow.shape
+    E = weight.shape[0]
+    flow = flow.float().contiguous()
+    w = weight.reshape(E, 2).float().contiguous()
+    bvec = bias.float().contiguous()
+    if out is None:
+        out = torch.empty((B, E, H, W), dtype=dtype, device=flow.device)
+    lo, po, o = feat_layout(out)
+    if o is not out:
+        raise ValueError("out must be contiguous or channels-last")
+    check(_lib.load().roma_disp_emb(_p(flow), _p(w), _p(bvec), _p(out), B, E, H, W, float(gain), _dt(out), lo, po, _stream()),
+          "roma_disp_emb")
+    return out
+
+
+def interp_bilinear(x, size):
+    """F.interpolate(x, size=size, mode='bilinear', align_corners=False) for fp32 (B,C,H,W) maps — matcher.py:349-360,408-417."""
+    _need_gpu(x)
+    B, C, Hi, Wi = x.shape
+    Ho, Wo = int(size[0]), int(size[1])
+    x = x.float().contiguous()
+    y = torch.empty((B, C, Ho, Wo), dtype=torch.float32, device=x.device)
+    check(_lib.load().roma_interp_bilinear(_p(x), _p(y), B * C, Hi, Wi, Ho, Wo, _stream()), "roma_interp_bilinear")
+    return y
+
+
+def flow_update(flow, certainty, delta, sx, sy):
+    """In place: flow += (sx*delta[:,0], sy*delta[:,1]); returns (flow, certainty + delta[:,2:3]) — matcher.py:397-402.
+    `certainty` may be None (the reference's 0.0 at the coarsest scale)."""
+    _need_gpu(flow, certainty, delta)
+    B, _, H, W = flow.shape
+    assert flow.dtype == torch.float32 and flow.is_contiguous() and delta.dtype == torch.float32 and delta.is_contiguous()
+    cert_in = None if certainty is None else certainty.float().contiguous()
+    cert = torch.empty((B, 1, H, W), dtype=torch.float32, device=flow.device)
+    check(_lib.load().roma_flow_update(_p(flow), _p(cert), _p(cert_in), _p(delta), B, H, W, float(sx), float(sy), _stream()),
+          "roma_flow_update")
+    return flow, cert
+
+
+def cls_to_flow_refine(cls):
+    """romatch/utils/utils.py:301-323.  cls (B,C,H,W) logits (any strides) -> (B,H,W,2) fp32."""
+    _need_gpu(cls)
+    B, C, H, W = cls.shape
+    sb, sc, sh, sw = cls.stride()
+    if sh != W * sw:
+        cls = cls.contiguous()
+        sb, sc, sh, sw = cls.stride()
+    flow = torch.empty((B, 2, H, W), dtype=torch.float32, device=cls.device)
+    check(_lib.load().roma_cls_to_flow_refine(_p(cls), _p(flow), None, B, C, H * W, sb, sc, sw, _dt(cls), _stream()),
+          "roma_cls_to_flow_refine")
+    return flow.permute(0, 2, 3, 1)
+
+
+def cls_rows_to_flow(rows, B, H, W):
+    """Token-major logits straight from `to_out`: rows (B, H*W, C+1) -> flow (B,2,H,W), certainty (B,1,H,W), fp32.
+    transformer/__init__.py:42-45 + utils.py:301-323 + matcher.py:383-385 in one kernel."""
+    _need_gpu(rows)
+    assert rows.dim() == 3 and rows.shape[0] == B and rows.shape[1] == H * W and rows.stride(2) == 1
+    C = rows.shape[2] - 1
+    flow = torch.empty((B, 2, H, W), dtype=torch.float32, device=rows.device)
+    cert = torch.empty((B, 1, H, W), dtype=torch.float32, device=rows.device)
+    check(_lib.load().roma_cls_to_flow_refine(_p(rows), _p(flow), _p(cert), B, C, H * W, rows.stride(0), 1, rows.stride(1),
+                                              _dt(rows), _stream()), "roma_cls_to_flow_refine")
+    return flow, cert
+
+
+def cos_kernel(x, y, T=0.2, eps=1e-6, diag_add=0.0):
+    """CosKernel.__call__ — matcher.py:154-163.  x (B,N,D), y (B,M,D) -> (B,N,M) fp32, on the fp32 MFMA."""
+    _need_gpu(x, y)
+    x = x.float().contiguous()
+    y = y.float().contiguous()
+    B, N, D = x.shape
+    M = y.shape[1]
+    K = torch.empty((B, N, M), dtype=torch.float32, device=x.device)
+    check(_lib.load().roma_cos_kernel(_p(x), _p(y), _p(K), B, N, M, D, float(T), float(eps), float(diag_add), _stream()),
+          "roma_cos_kernel")
+    return K
+
+
+def match_finalize(flow, certainty, cert16, symmetric=True):
+    """match() post-processing — matcher.py:656-662, 684-718.  Returns warp (P,H,2W|W,4), certainty (P,H,2W|W)."""
+    _need_gpu(flow, certainty, cert16)
+    B, _, H, W = flow.shape
+    P = B // 2 if symmetric else B
+    flow = flow.float().contiguous()
+    certainty = certainty.float().contiguous()
+    H16 = W16 = 0
+    if cert16 is not None:
+        cert16 = cert16.float().contiguous()
+        H16, W16 = cert16.shape[-2:]
+    WW = 2 * W if symmetric else W
+    warp = torch.empty((P, H, WW, 4), dtype=torch.float32, device=flow.device)
+    cert = torch.empty((P, H, WW), dtype=torch.float32, device=flow.device)
+    check(_lib.load().roma_match_finalize(_p(flow), _p(certainty), _p(cert16), _p(warp), _p(cert), P, H, W, H16, W16,
+                                          1 if symmetric else 0, _stream()), "roma_match_finalize")
+    return warp, cert
+
+
+def kde(x, std=0.1, half=True, down=None):
+    """romatch/utils/kde.py:4-12.  half=True rounds the coordinates to fp16 first (as the reference does) and returns
+    fp16; the pairwise sums themselves are fp32 (the reference's fp16 cdist is NOT reproduced bit for bit)."""
+    _need_gpu(x)
+    if x.dim() != 2 or x.shape[1] != 4:
+        raise ValueError("kde expects (N,4) matches")
+    xs = (x.half() if half else x).float().contiguous()
+    N = xs.shape[0]
+    dens = torch.empty((N,), dtype=torch.float32, device=x.device)
+    check(_lib.load().roma_kde_density(_p(xs), _p(dens), N, int(down or 1), float(std), _stream()), "roma_kde_density")
+    return dens.half() if half else dens
+
+
+def dwconv5x5_bn_relu(x, w25, scale, shift, out=None):
+    """relu(BN(depthwise5x5(x))) with BN folded into (scale, shift) — matcher.py:77-103.  x, out: channels-last
+    (B,C,H,W) views; w25 (25,C) fp32 tap-major."""
+    _need_gpu(x, w25, scale, shift, out)
+    B, C, H, W = x.shape
+    lx, px, xx = feat_layout(x)
+    if lx != ROMA_NHWC:
+        raise ValueError("dwconv5x5_bn_relu needs channels-last input")
+    if out is None:
+        out = nhwc_empty(B, C, H, W, x.dtype, x.device, pitch=px)
+    lo, po, o = feat_layout(out)
+    if lo != ROMA_NHWC or o is not out:
+        raise ValueError("dwconv5x5_bn_relu needs channels-last output")
+    check(_lib.load().roma_dwconv5x5_bn_relu(_p(xx), _p(w25), _p(scale), _p(shift), _p(out), B, C, H, W, _dt(xx), px, po, _stream()),
+          "roma_dwconv5x5_bn_relu")
+    return out
+
+
+def tiny_corr_posembed(f0, f1, exact=False):
+    """TinyRoMa.corr_volume + pos_embed fused — tiny.py:241-254,178-203.  f0 (B,C,H0,W0), f1 (B,C,H1,W1) -> (B,2,H0,W0)."""
+    _need_gpu(f0, f1)
+    B, C, H0, W0 = f0.shape
+    _, _, H1, W1 = f1.shape
+    a = f0.float().permute(0, 2, 3, 1).contiguous()
+    b = f1.float().permute(0, 2, 3, 1).contiguous()
+    out = torch.empty((B, 2, H0, W0), dtype=torch.float32, device=f0.device)
+    check(_lib.load().roma_tiny_corr_posembed(_p(a), _p(b), _p(out), B, C, H0, W0, H1, W1, 1 if exact else 0, _stream()),
+          "roma_tiny_corr_posembed")
+    return out

@@ -1,0 +1,48 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/roma_hip.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+
+from roma_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "roma_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(roma_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    assert declared_symbols() == sorted(_lib.SIGNATURES)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared_symbols():
+        assert hasattr(lib, name), name
+
+
+def test_version_and_error_string():
+    lib = _lib.load()
+    assert lib.roma_abi_version() == 1
+    assert isinstance(lib.roma_last_error(), bytes)
+
+
+def test_argument_validation_needs_no_gpu():
+    lib = _lib.load()
+    rc = lib.roma_local_corr(None, None, None, None, 1, 8, 4, 4, 2, 0, 0, 8, 8, 0, 25, None)
+    assert rc == -1 and b"null pointer" in lib.roma_last_error()
+    rc = lib.roma_kde_density(None, None, 0, 1, 0.1, None)
+    assert rc < 0
+
+
+def test_ops_refuse_cpu_tensors():
+    import pytest
+    import torch
+    from roma_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.kde(torch.zeros(8, 4))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.cls_to_flow_refine(torch.zeros(1, 64, 2, 2))

@@ -1,0 +1,270 @@
+"""HIP kernels (through the C ABI / ctypes binding) against the CPU oracle and the reference's golden vectors.
+Run with -m gpu on an MI355X.  Tolerances: fp32 storage 2e-5 abs on O(1) values (different summation order only);
+fp16/bf16 storage is compared with the oracle fed the SAME rounded inputs, tolerance = output rounding."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as H
+from tests.golden import cases, recipes as R
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+DEV = "cuda"
+
+
+def _ops():
+    from roma_amd import ops
+    return ops
+
+
+def _O():
+    from oracle import roma_oracle as O
+    return O
+
+
+def maxerr(a, b):
+    return float((a.detach().float().cpu() - b.detach().float().cpu()).abs().max())
+
+
+def test_library_is_loaded_and_on_gpu():
+    from roma_amd import _lib
+    assert _lib.load().roma_abi_version() == 1
+    assert torch.cuda.is_available()
+    with pytest.raises(RuntimeError):
+        _ops().local_correlation(torch.zeros(1, 8, 4, 4), torch.zeros(1, 8, 4, 4), 2)     # CPU tensors: loud failure
+
+
+# ---- local_correlation -------------------------------------------------------------------------
+@pytest.mark.parametrize("name", list(cases.LOCAL_CORR_CASES))
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+def test_local_corr_golden_fp32(name, layout):
+    g = H.golden("local_corr")
+    f0, f1, flow, r = cases.local_corr_inputs(name)
+    a, b = H.T(f0, DEV), H.T(f1, DEV)
+    if layout == "nhwc":
+        a, b = a.contiguous(memory_format=torch.channels_last), b.contiguous(memory_format=torch.channels_last)
+    out = _ops().local_correlation(a, b, r, flow=None if flow is None else H.T(flow, DEV))
+    assert out.shape == g[name].shape
+    assert maxerr(out, H.T(g[name])) < 2e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("name", ["r7_coh", "r3_adv", "r2_coh"])
+def test_local_corr_low_precision_storage(name, dtype):
+    f0, f1, flow, r = cases.local_corr_inputs(name)
+    a, b = H.T(f0).to(dtype), H.T(f1).to(dtype)
+    ref = _O().local_correlation(a.float(), b.float(), r, flow=H.T(flow))
+    out = _ops().local_correlation(a.to(DEV).contiguous(memory_format=torch.channels_last),
+                                   b.to(DEV).contiguous(memory_format=torch.channels_last), r, flow=H.T(flow, DEV))
+    assert out.dtype == dtype
+    tol = (2 ** -10 if dtype == torch.float16 else 2 ** -7) * max(1.0, float(ref.abs().max()))
+    assert maxerr(out, ref) <= tol
+
+
+@pytest.mark.parametrize("shape", [(2, 512, 40, 40, 7), (2, 512, 70, 70, 3), (2, 256, 140, 140, 2), (1, 256, 37, 53, 2), (1, 64, 9, 200, 5)])
+def test_local_corr_full_sizes_vs_oracle(shape):
+    B, C, h, w, r = shape
+    f0 = R.normal(f"lcfull.{shape}.f0", (B, C, h, w))
+    f1 = R.normal(f"lcfull.{shape}.f1", (B, C, h, w))
+    flow = R.coherent_flow(f"lcfull.{shape}.flow", B, h, w)
+    ref = _O().local_correlation(H.T(f0), H.T(f1), r, flow=H.T(flow))
+    out = _ops().local_correlation(H.T(f0, DEV).contiguous(memory_format=torch.channels_last),
+                                   H.T(f1, DEV).contiguous(memory_format=torch.channels_last), r, flow=H.T(flow, DEV))
+    assert maxerr(out, ref) < 5e-5
+
+
+def test_local_corr_full_size_golden_l16():
+    g = H.golden("local_corr")
+    B, C, h, w, r = 2, 512, 40, 40, 7
+    out = _ops().local_correlation(H.T(R.normal("lc.full16.f0", (B, C, h, w)), DEV), H.T(R.normal("lc.full16.f1", (B, C, h, w)), DEV), r,
+                                   flow=H.T(R.coherent_flow("lc.full16.flow", B, h, w), DEV)).cpu().numpy()
+    assert np.abs(out[:, ::7, ::3, ::3] - g["full16_sample"]).max() < 5e-5
+    np.testing.assert_allclose(R.checksum(out)[:3], g["full16_stats"][:3], rtol=1e-5, atol=1e-2)
+
+
+def test_local_corr_properties_at_bench_size():
+    """Size-independent properties at the largest 560->864 call (U4: 256ch, 216x216, r=2), fp16 channels-last:
+    linearity in f0, identity flow centre tap == <f0,f1>/sqrt(C), zero outside the image."""
+    ops = _ops()
+    B, C, h, w, r = 2, 256, 216, 216, 2
+    gen = torch.Generator(device="cpu").manual_seed(0)
+    f0 = torch.randn(B, C, h, w, generator=gen).half().to(DEV).contiguous(memory_format=torch.channels_last)
+    f1 = torch.randn(B, C, h, w, generator=gen).half().to(DEV).contiguous(memory_format=torch.channels_last)
+    flow = H.T(R.coherent_flow("lcprop.flow", B, h, w), DEV)
+    a = ops.local_correlation(f0, f1, r, flow=flow).float()
+    b2 = ops.local_correlation(f0 * 2, f1, r, flow=flow).float()
+    assert maxerr(b2, 2 * a) <= 2e-3 * float(a.abs().max())
+    ident = ops.local_correlation(f0, f1, r, flow=None).float()
+    centre = (f0.float() * f1.float()).sum(1) / math.sqrt(C)
+    assert maxerr(ident[:, (2 * r + 1) ** 2 // 2], centre) <= 2e-3 * float(centre.abs().max())
+    far = torch.full((B, 2, h, w), 3.0, device=DEV)
+    assert float(ops.local_correlation(f0, f1, r, flow=far).abs().max()) == 0.0
+
+
+def test_local_corr_writes_into_concat_slice():
+    ops = _ops()
+    B, C, h, w, r = 1, 32, 10, 12, 2
+    K = 25
+    f0, f1 = torch.randn(B, C, h, w, device=DEV), torch.randn(B, C, h, w, device=DEV)
+    flow = H.T(R.coherent_flow("lcslice.flow", B, h, w), DEV)
+    buf = torch.zeros(B, h, w, 2 * C + K + 7, device=DEV)
+    d = buf.permute(0, 3, 1, 2)
+    d[:, :C] = f0
+    d[:, C:2 * C] = f1
+    ops.local_correlation(d[:, :C], d[:, C:2 * C], r, flow=flow, out=d[:, 2 * C:2 * C + K])
+    ref = ops.local_correlation(f0, f1, r, flow=flow)
+    assert maxerr(d[:, 2 * C:2 * C + K], ref) < 1e-6
+    assert float(buf[..., 2 * C + K:].abs().max()) == 0.0
+
+
+def test_local_corr_argument_errors():
+    ops = _ops()
+    f = torch.zeros(1, 8, 4, 4, device=DEV)
+    with pytest.raises(ValueError):
+        ops.local_correlation(f, f, 9)
+    with pytest.raises(NotImplementedError):
+        ops.local_correlation(f, f, 2, padding_mode="border")
+    with pytest.raises(ValueError):
+        ops.local_correlation(f, f, 2, flow=torch.zeros(1, 2, 5, 4, device=DEV))
+
+
+# ---- warp / interp / disp_emb ------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("C,layout", [(64, "nhwc"), (9, "nhwc"), (12, "nchw")])
+def test_warp_bilinear(dtype, C, layout):
+    import torch.nn.functional as F
+    B, h, w = 2, 17, 23
+    src = H.T(R.normal(f"warp.src.{C}", (B, C, h, w))).to(dtype)
+    flow = H.T(R.adversarial_flow("warp.flow", B, h + 3, w - 2, lim=1.1))
+    ref = F.grid_sample(src.float(), flow.permute(0, 2, 3, 1), mode="bilinear", align_corners=False)
+    s = src.to(DEV)
+    if layout == "nhwc":
+        s = s.contiguous(memory_format=torch.channels_last)
+    out = _ops().warp_bilinear(s, flow.to(DEV))
+    assert maxerr(out, ref) <= (1e-5 if dtype == torch.float32 else 4e-3)
+
+
+@pytest.mark.parametrize("sizes", [((40, 40), (70, 70)), ((70, 70), (140, 140)), ((560, 560), (108, 108)), ((5, 6), (30, 36)), ((7, 9), (7, 9))])
+def test_interp_bilinear(sizes):
+    import torch.nn.functional as F
+    (hi, wi), (ho, wo) = sizes
+    x = H.T(R.normal(f"interp.{sizes}", (2, 3, hi, wi)))
+    ref = F.interpolate(x, size=(ho, wo), mode="bilinear", align_corners=False)
+    assert maxerr(_ops().interp_bilinear(x.to(DEV), (ho, wo)), ref) < 2e-6
+
+
+def test_disp_emb_and_flow_update():
+    O = _O()
+    B, E, h, w = 2, 6, 11, 13
+    flow = H.T(R.coherent_flow("de.flow", B, h, w))
+    wgt, bias = H.T(R.normal("de.w", (E, 2, 1, 1))), H.T(R.normal("de.b", (E,)))
+    ref = torch.nn.functional.conv2d(1.25 * 1.5 * (flow - O.pixel_grid(B, h, w)), wgt, bias)
+    out = _ops().disp_emb(flow.to(DEV), wgt.to(DEV), bias.to(DEV), 1.25 * 1.5)
+    assert maxerr(out, ref) < 1e-5
+    delta = H.T(R.normal("de.delta", (B, 3, h, w)))
+    cert = H.T(R.normal("de.cert", (B, 1, h, w)))
+    f2, c2 = _ops().flow_update(flow.clone().to(DEV), cert.to(DEV), delta.to(DEV), 0.01, 0.02)
+    assert maxerr(f2, flow + torch.stack((0.01 * delta[:, 0], 0.02 * delta[:, 1]), 1)) < 1e-6
+    assert maxerr(c2, cert + delta[:, 2:]) < 1e-6
+
+
+# ---- cls_to_flow_refine ------------------------------------------------------------------------
+def test_cls_to_flow_refine_golden_both_layouts():
+    g = H.golden("cls_to_flow_refine")
+    x = H.T(cases.cls_inputs(), DEV)
+    assert maxerr(_ops().cls_to_flow_refine(x), H.T(g["flow"])) < 2e-6                         # planar (reference layout)
+    rows = x.permute(0, 2, 3, 1).reshape(2, 64, 4096)
+    rows = torch.cat((rows, torch.full((2, 64, 1), 0.25, device=DEV)), dim=2).contiguous()      # token-major + certainty logit
+    flow, cert = _ops().cls_rows_to_flow(rows, 2, 8, 8)
+    assert maxerr(flow.permute(0, 2, 3, 1), H.T(g["flow"])) < 2e-6
+    assert float((cert - 0.25).abs().max()) == 0.0
+    xs = H.T(cases.cls_inputs(res=8, B=1, H=5, W=7), DEV)
+    assert maxerr(_ops().cls_to_flow_refine(xs), H.T(g["flow_small"])) < 2e-6
+
+
+def test_cls_to_flow_refine_full_size_fp16():
+    O = _O()
+    x = (H.T(R.normal("clsfull", (2, 4096, 40, 40))) * 3).half()
+    ref = O.cls_to_flow_refine(x.float())
+    rows = torch.cat((x.permute(0, 2, 3, 1).reshape(2, 1600, 4096), torch.zeros(2, 1600, 1, dtype=torch.half)), dim=2).to(DEV)
+    flow, _ = _ops().cls_rows_to_flow(rows, 2, 40, 40)
+    assert maxerr(flow.permute(0, 2, 3, 1), ref) < 1e-5
+
+
+# ---- CosKernel (MFMA) --------------------------------------------------------------------------
+@pytest.mark.parametrize("name,dims", [("small", (1, 512, 10, 10)), ("rect", (2, 64, 6, 9))])
+def test_cos_kernel_golden(name, dims):
+    g = H.golden("gp")
+    b, c, h, w = dims
+    x = H.T(R.normal(f"gp.{name}.x", (b, c, h, w)), DEV).flatten(2).transpose(1, 2)
+    y = H.T(R.normal(f"gp.{name}.y", (b, c, h, w)), DEV).flatten(2).transpose(1, 2)
+    assert maxerr(_ops().cos_kernel(x, y), H.T(g[f"{name}_Kxy"])) < 2e-6
+
+
+def test_cos_kernel_full_size_asymmetric_and_diag():
+    O = _O()
+    x = H.T(R.normal("cosfull.x", (2, 1600, 512)))
+    y = H.T(R.normal("cosfull.y", (2, 1600, 512))) * H.T(R.uniform("cosfull.s", (2, 1600, 1), 0.5, 2.0))
+    assert maxerr(_ops().cos_kernel(x.to(DEV), y.to(DEV)), O.cos_kernel(x, y)) < 2e-6
+    kyy = _ops().cos_kernel(y.to(DEV), y.to(DEV), diag_add=0.1)
+    assert maxerr(kyy, O.cos_kernel(y, y) + 0.1 * torch.eye(1600)[None]) < 2e-6
+
+
+# ---- match_finalize / kde ----------------------------------------------------------------------
+def test_match_finalize_golden():
+    g = H.golden("match_post")
+    c16, flow, cert = cases.post_inputs()
+    warp, certainty = _ops().match_finalize(H.T(flow, DEV), H.T(cert, DEV), H.T(c16, DEV), symmetric=True)
+    assert maxerr(warp[0], H.T(g["warp"])) < 1e-6
+    assert maxerr(certainty[0], H.T(g["certainty"])) < 1e-6
+
+
+def test_kde_golden_and_full_size():
+    O = _O()
+    g = H.golden("kde")
+    x = H.T(cases.kde_inputs(), DEV)
+    assert maxerr(_ops().kde(x, half=False), H.T(g["fp32"])) < 1e-3
+    assert maxerr(_ops().kde(x, half=False, down=4), H.T(g["down4"])) < 1e-3
+    # half=True: reference does the whole cdist in fp16; ours rounds the inputs to fp16 and sums in fp32.
+    d16 = _ops().kde(x, half=True)
+    assert d16.dtype == torch.float16
+    rel = ((d16.float().cpu() - H.T(g["fp16"])).abs() / H.T(g["fp16"]).abs().clamp_min(1)).max()
+    assert float(rel) < 2e-2
+    xf = H.T(R.uniform("kdefull", (10000, 4), -1, 1))
+    ref = O.kde(xf, half=False)
+    out = _ops().kde(xf.to(DEV), half=False)
+    assert float(((out.cpu() - ref).abs() / ref).max()) < 1e-4
+
+
+# ---- depthwise 5x5 + BN + ReLU -----------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("C,h,w", [(24, 19, 21), (576, 12, 10), (144, 7, 33)])
+def test_dwconv5x5_bn_relu(dtype, C, h, w):
+    import torch.nn.functional as F
+    B = 2
+    x = H.T(R.normal(f"dw.x.{C}", (B, C, h, w))).to(dtype)
+    wt = H.T(R.normal(f"dw.w.{C}", (C, 1, 5, 5), scale=0.2))
+    scale, shift = H.T(R.uniform("dw.sc", (C,), 0.5, 1.5)), H.T(R.normal("dw.sh", (C,), scale=0.1))
+    ref = F.relu(F.conv2d(x.float(), wt, None, 1, 2, groups=C) * scale[None, :, None, None] + shift[None, :, None, None])
+    out = _ops().dwconv5x5_bn_relu(x.to(DEV).contiguous(memory_format=torch.channels_last),
+                                   wt.reshape(C, 25).t().contiguous().to(DEV), scale.to(DEV), shift.to(DEV))
+    assert maxerr(out, ref) <= (2e-5 if dtype == torch.float32 else 4e-3)
+
+
+# ---- TinyRoMa fused corr + pos_embed -----------------------------------------------------------
+def test_tiny_corr_posembed_golden():
+    g = H.golden("tiny")
+    f0, f1 = H.T(R.normal("tiny.f0", (2, 64, 8, 12)), DEV), H.T(R.normal("tiny.f1", (2, 64, 8, 12)), DEV)
+    assert maxerr(_ops().tiny_corr_posembed(f0, f1, exact=True), H.T(g["pos_embed_exact_b2"])) < 1e-5
+    assert maxerr(_ops().tiny_corr_posembed(f0[:1], f1[:1], exact=False), H.T(g["pos_embed_fast_b1"])) < 1e-5
+
+
+def test_tiny_corr_posembed_full_size():
+    O = _O()
+    f0, f1 = H.T(R.normal("tinyfull.f0", (1, 64, 60, 80))) * 2, H.T(R.normal("tinyfull.f1", (1, 64, 60, 80))) * 2
+    cv = O.tiny_corr_volume(f0, f1)
+    assert maxerr(_ops().tiny_corr_posembed(f0.to(DEV), f1.to(DEV), exact=True), O.tiny_pos_embed(cv, True)) < 2e-5
+    assert maxerr(_ops().tiny_corr_posembed(f0.to(DEV), f1.to(DEV), exact=False), O.tiny_pos_embed(cv, False)) < 2e-5

@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Per-kernel micro-benchmarks on one MI355X (HIP events on the launch stream).  Prints one line per case:
+algorithmic bytes, time, GB/s, fraction of the 8 TB/s HBM spec."""
+import argparse
+import math
+import sys
+import os
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from roma_amd import ops  # noqa: E402
+from tests.golden import recipes as R  # noqa: E402
+
+LC_SHAPES = [("L16", 512, 40, 7), ("L8", 512, 70, 3), ("L4", 256, 140, 2), ("U8", 512, 108, 3), ("U4", 256, 216, 2)]
+PEAK = 8.0e12
+
+
+def timeit(fn, iters=50, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e-3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pairs", type=int, default=1)
+    ap.add_argument("--dtype", default="f16")
+    ap.add_argument("--flow", default="coherent")
+    args = ap.parse_args()
+    dt = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[args.dtype]
+    es = 4 if dt == torch.float32 else 2
+    B = 2 * args.pairs
+    tot_b = tot_t = 0
+    for name, C, h, r in LC_SHAPES:
+        K = (2 * r + 1) ** 2
+        f0 = torch.randn(B, C, h, h, device="cuda").to(dt).contiguous(memory_format=torch.channels_last)
+        f1 = torch.randn(B, C, h, h, device="cuda").to(dt).contiguous(memory_format=torch.channels_last)
+        if args.flow == "coherent":
+            flow = torch.from_numpy(R.coherent_flow("bench", B, h, h)).cuda()
+        else:
+            flow = torch.from_numpy(R.adversarial_flow("bench", B, h, h)).cuda()
+        out = ops.nhwc_empty(B, K, h, h, dt, "cuda")
+        t = timeit(lambda: ops.local_correlation(f0, f1, r, flow=flow, out=out))
+        nbytes = 2 * B * C * h * h * es + B * 2 * h * h * 4 + B * K * h * h * es
+        tot_b += nbytes
+        tot_t += t
+        print(f"local_corr {name:4s} C={C} h={h} r={r} B={B} {args.dtype} {args.flow}: {t*1e6:8.1f} us  {nbytes/1e6:8.2f} MB  "
+              f"{nbytes/t/1e9:8.1f} GB/s  {nbytes/t/PEAK*100:5.1f}% of 8TB/s", flush=True)
+    print(f"local_corr ALL5: {tot_t*1e6:.1f} us  {tot_b/1e6:.2f} MB  {tot_b/tot_t/1e9:.1f} GB/s  {tot_b/tot_t/PEAK*100:.1f}%")
+
+    # depthwise conv at the refiner shapes
+    for D, h in [(1384, 40), (1144, 70), (576, 140), (144, 280), (24, 560), (1144, 108), (576, 216), (144, 432), (24, 864)]:
+        x = torch.randn(B, D, h, h, device="cuda").to(dt).contiguous(memory_format=torch.channels_last)
+        w = torch.randn(25, D, device="cuda")
+        sc, sh = torch.rand(D, device="cuda") + 0.5, torch.randn(D, device="cuda")
+        y = torch.empty_like(x)
+        t = timeit(lambda: ops.dwconv5x5_bn_relu(x, w, sc, sh, out=y), iters=20)
+        nb = 2 * B * D * h * h * es
+        print(f"dwconv D={D} h={h}: {t*1e6:8.1f} us {nb/1e6:8.2f} MB {nb/t/1e9:8.1f} GB/s", flush=True)
+
+    # cos kernel, cls refine, kde
+    x = torch.randn(B, 1600, 512, device="cuda")
+    y = torch.randn(B, 1600, 512, device="cuda")
+    t = timeit(lambda: ops.cos_kernel(x, y), iters=20)
+    print(f"cos_kernel B={B} 1600x1600x512 fp32-MFMA: {t*1e6:.1f} us  {2*B*1600*1600*512/t/1e12:.1f} TFLOP/s")
+    rows = torch.randn(B, 1600, 4097, device="cuda").to(dt)
+    t = timeit(lambda: ops.cls_rows_to_flow(rows, B, 40, 40), iters=20)
+    print(f"cls_rows_to_flow: {t*1e6:.1f} us  {rows.numel()*es/t/1e9:.1f} GB/s")
+    pts = torch.rand(40000, 4, device="cuda") * 2 - 1
+    t = timeit(lambda: ops.kde(pts, half=True), iters=5, warm=1)
+    print(f"kde N=40000: {t*1e3:.3f} ms  {40000*40000/t/1e12:.2f} T pair-exp/s")
+
+
+if __name__ == "__main__":
+    main()
