@@ -11,49 +11,6 @@
 namespace roma {
 namespace {
 
-template <typename T> __device__ __forceinline__ void unpack16(const u32x4& v, float* f);
-template <> __device__ __forceinline__ void unpack16<float>(const u32x4& v, float* f) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) f[i] = __uint_as_float(v[i]);
-}
-template <> __device__ __forceinline__ void unpack16<half_t>(const u32x4& v, float* f) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const half2_t h = __builtin_bit_cast(half2_t, v[i]);
-    f[2 * i] = (float)h[0];
-    f[2 * i + 1] = (float)h[1];
-  }
-}
-template <> __device__ __forceinline__ void unpack16<bf16_t>(const u32x4& v, float* f) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    f[2 * i] = __uint_as_float(v[i] << 16);
-    f[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
-  }
-}
-template <typename T> __device__ __forceinline__ u32x4 pack16(const float* f);
-template <> __device__ __forceinline__ u32x4 pack16<float>(const float* f) {
-  return u32x4{__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3])};
-}
-template <> __device__ __forceinline__ u32x4 pack16<half_t>(const float* f) {
-  u32x4 v;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    half2_t h{(half_t)f[2 * i], (half_t)f[2 * i + 1]};
-    v[i] = __builtin_bit_cast(uint32_t, h);
-  }
-  return v;
-}
-template <> __device__ __forceinline__ u32x4 pack16<bf16_t>(const float* f) {
-  u32x4 v;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    bf162_t h{(bf16_t)f[2 * i], (bf16_t)f[2 * i + 1]};
-    v[i] = __builtin_bit_cast(uint32_t, h);
-  }
-  return v;
-}
-
 constexpr int XS = 4;
 
 template <typename T>

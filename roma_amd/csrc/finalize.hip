@@ -6,23 +6,6 @@
 namespace roma {
 namespace {
 
-__device__ __forceinline__ float pix_center(int i, int n) {
-  const float start = -1.f + 1.f / n, end = 1.f - 1.f / n;
-  if (n == 1) return start;
-  const float step = (end - start) / (float)(n - 1);
-  return (i < n / 2) ? start + step * i : end - step * (n - 1 - i);
-}
-
-__device__ __forceinline__ void interp_src(int d, int in, int out, int& i0, int& i1, float& l1) {
-  const float scale = (float)in / (float)out;
-  float s = scale * (d + 0.5f) - 0.5f;
-  s = s < 0.f ? 0.f : s;
-  i0 = (int)s;
-  if (i0 > in - 1) i0 = in - 1;
-  i1 = i0 + (i0 < in - 1 ? 1 : 0);
-  l1 = s - (float)i0;
-}
-
 __global__ __launch_bounds__(256) void finalize_kernel(const float* __restrict__ flow, const float* __restrict__ cert,
                                                        const float* __restrict__ cert16, float* __restrict__ warp,
                                                        float* __restrict__ certainty, int P, int H, int W, int H16, int W16,

@@ -117,8 +117,8 @@ __global__ __launch_bounds__(kThreads) void local_corr_kernel(LCParams p) {
   }
   __syncthreads();
   const int bx0 = s_meta[0], by0 = s_meta[1];
-  int bw = s_meta[2] - bx0 + 1, bh = s_meta[3] - by0 + 1;
-  if (bw < 0 || bh < 0) bw = bh = 0;                           // every window is outside the image
+  const bool empty = s_meta[2] < bx0 || s_meta[3] < by0;       // every window of the tile is outside the image
+  const int bw = empty ? 0 : s_meta[2] - bx0 + 1, bh = empty ? 0 : s_meta[3] - by0 + 1;
   const int nrows = bw * bh;
   const bool staged = nrows <= p.max_rows;                     // else: read f1 rows from global memory directly
   const int zero_row = staged ? nrows : 0;
@@ -254,7 +254,8 @@ __global__ __launch_bounds__(kThreads) void local_corr_kernel(LCParams p) {
 template <typename T, int R>
 int launch_lc(LCParams p, hipStream_t stream) {
   using G = LCGeom<R>;
-  constexpr int CC = 64 * 2 / sizeof(T) >= 64 ? 64 : 32;      // 128-byte LDS rows: 64 halves / 32 floats
+  // LDS row = one position's channel chunk: 128 bytes for small windows, 64 bytes for r >= 4 (more rows fit)
+  constexpr int CC = (R >= 4 ? 64 : 128) / (int)sizeof(T);
   constexpr int TP = G::TW * G::TH, Q = (2 * R + 2) * (2 * R + 2);
   constexpr int ROWB = (CC / ElemTraits<T>::kPer16B + 1) * 16;
   p.tiles_x = (p.W + G::TW - 1) / G::TW;

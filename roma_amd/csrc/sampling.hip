@@ -8,57 +8,6 @@
 namespace roma {
 namespace {
 
-// torch.linspace(-1+1/n, 1-1/n, n)[i], evaluated the way ATen does (symmetric around the midpoint)
-__device__ __forceinline__ float pix_center(int i, int n) {
-  const float start = -1.f + 1.f / n, end = 1.f - 1.f / n;
-  if (n == 1) return start;
-  const float step = (end - start) / (float)(n - 1);
-  return (i < n / 2) ? start + step * i : end - step * (n - 1 - i);
-}
-
-template <typename T> __device__ __forceinline__ void unpack16(const u32x4& v, float* f);
-template <> __device__ __forceinline__ void unpack16<float>(const u32x4& v, float* f) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) f[i] = __uint_as_float(v[i]);
-}
-template <> __device__ __forceinline__ void unpack16<half_t>(const u32x4& v, float* f) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const half2_t h = __builtin_bit_cast(half2_t, v[i]);
-    f[2 * i] = (float)h[0];
-    f[2 * i + 1] = (float)h[1];
-  }
-}
-template <> __device__ __forceinline__ void unpack16<bf16_t>(const u32x4& v, float* f) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    f[2 * i] = __uint_as_float(v[i] << 16);
-    f[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
-  }
-}
-template <typename T> __device__ __forceinline__ u32x4 pack16(const float* f);
-template <> __device__ __forceinline__ u32x4 pack16<float>(const float* f) {
-  return u32x4{__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3])};
-}
-template <> __device__ __forceinline__ u32x4 pack16<half_t>(const float* f) {
-  u32x4 v;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    half2_t h{(half_t)f[2 * i], (half_t)f[2 * i + 1]};
-    v[i] = __builtin_bit_cast(uint32_t, h);
-  }
-  return v;
-}
-template <> __device__ __forceinline__ u32x4 pack16<bf16_t>(const float* f) {
-  u32x4 v;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    bf162_t h{(bf16_t)f[2 * i], (bf16_t)f[2 * i + 1]};
-    v[i] = __builtin_bit_cast(uint32_t, h);
-  }
-  return v;
-}
-
 struct Corner {
   int x0, y0;
   float w00, w01, w10, w11;  // wYX
@@ -189,17 +138,6 @@ __global__ __launch_bounds__(256) void disp_emb_kernel(const float* __restrict__
     const size_t o = dst_nhwc ? (((size_t)b * H + y) * W + x) * dst_pitch + e : (((size_t)b * dst_pitch + e) * H + y) * W + x;
     dst[o] = from_f32<T>(v);
   }
-}
-
-// ATen upsample_bilinear2d, align_corners=False: src = max((dst+0.5)*in/out-0.5, 0)
-__device__ __forceinline__ void interp_src(int d, int in, int out, int& i0, int& i1, float& l1) {
-  const float scale = (float)in / (float)out;
-  float s = scale * (d + 0.5f) - 0.5f;
-  s = s < 0.f ? 0.f : s;
-  i0 = (int)s;
-  if (i0 > in - 1) i0 = in - 1;
-  i1 = i0 + (i0 < in - 1 ? 1 : 0);
-  l1 = s - (float)i0;
 }
 
 __global__ __launch_bounds__(256) void interp_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int Hi, int Wi,

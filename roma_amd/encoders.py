@@ -1,0 +1,92 @@
+"""Feature pyramids: VGG19-BN (scales 1,2,4,8) + frozen DINOv2 ViT-L/14 ("scale 16").
+Reference: romatch/models/encoders.py:61-122.  Library convolutions/GEMMs on PyTorch-ROCm (MIOpen / hipBLASLt),
+channels-last, BatchNorm folded into the convolutions at prepare time, in the model's amp dtype."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .transformer import DinoViT
+
+VGG19_CFG = [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M"]
+
+
+class VGG19(nn.Module):
+    """Parameters live in `layers.{0..39}` exactly like torchvision's vgg19_bn().features[:40] (encoders.py:64)."""
+
+    def __init__(self):
+        super().__init__()
+        layers, c = [], 3
+        for v in VGG19_CFG:
+            if v == "M":
+                layers.append(nn.MaxPool2d(2, 2))
+            else:
+                layers += [nn.Conv2d(c, v, 3, padding=1), nn.BatchNorm2d(v), nn.ReLU(inplace=True)]
+                c = v
+        self.layers = nn.ModuleList(layers[:40])
+        self._folded = None
+
+    def fold(self, dtype):
+        """conv+BN(eval) -> one conv: w' = w*g/sqrt(var+eps), b' = (b-mean)*g/sqrt(var+eps)+beta.  Cached."""
+        key = (dtype, self.layers[0].weight.device, tuple(p._version for p in self.parameters()))
+        if self._folded is not None and self._folded[0] == key:
+            return self._folded[1]
+        plan = []
+        i = 0
+        while i < len(self.layers):
+            m = self.layers[i]
+            if isinstance(m, nn.MaxPool2d):
+                plan.append(None)
+                i += 1
+                continue
+            bn = self.layers[i + 1]
+            s = bn.weight.float() / torch.sqrt(bn.running_var.float() + bn.eps)
+            w = (m.weight.float() * s[:, None, None, None]).to(dtype).contiguous(memory_format=torch.channels_last)
+            b = ((m.bias.float() - bn.running_mean.float()) * s + bn.bias.float()).to(dtype)
+            plan.append((w, b))
+            i += 3
+        self._folded = (key, plan)
+        return plan
+
+    @torch.no_grad()
+    def forward(self, x, dtype=torch.float16):
+        feats, scale = {}, 1
+        x = x.to(dtype).contiguous(memory_format=torch.channels_last)
+        for step in self.fold(dtype):
+            if step is None:
+                feats[scale] = x
+                scale *= 2
+                x = F.max_pool2d(x, 2, 2)
+            else:
+                x = F.relu_(F.conv2d(x, step[0], step[1], padding=1))
+        return feats
+
+
+class CNNandDinov2(nn.Module):
+    def __init__(self, dinov2: Optional[DinoViT] = None, amp_dtype=torch.float16):
+        super().__init__()
+        self.cnn = VGG19()
+        self.amp_dtype = amp_dtype
+        self.dinov2_vitl14 = [dinov2 if dinov2 is not None else DinoViT()]   # outside the module tree (encoders.py:104)
+
+    def train(self, mode: bool = True):
+        return self.cnn.train(mode)
+
+    def _vit(self, device):
+        v = self.dinov2_vitl14[0]
+        p = v.cls_token
+        if p.device != device or p.dtype != self.amp_dtype:
+            v = self.dinov2_vitl14[0] = v.to(device=device, dtype=self.amp_dtype).eval()
+        return v
+
+    @torch.no_grad()
+    def forward(self, x, upsample=False):
+        B, C, H, W = x.shape
+        pyr = self.cnn(x, self.amp_dtype)
+        if not upsample:                                                      # encoders.py:114
+            t = self._vit(x.device).patch_tokens(x.to(self.amp_dtype))
+            pyr[16] = t.reshape(B, H // 14, W // 14, -1).permute(0, 3, 1, 2)  # channels-last view of the token rows
+        return pyr

@@ -1,0 +1,460 @@
+"""RegressionMatcher / Decoder / GP / ConvRefiner of the RoMa hot path, MI355X-native.
+
+Same public surface as the reference's romatch/models/matcher.py (class names, constructor-visible attributes,
+`match / sample / to_pixel_coordinates / to_normalized_coordinates / match_keypoints / get_output_resolution /
+visualize_warp / forward / forward_symmetric`), same state-dict key layout, so `load_state_dict` of a reference
+checkpoint works unchanged.  What is different is underneath: the per-level arithmetic runs in the hand-written
+gfx950 kernels of libroma_hip.so (roma_amd.ops), activations are channels-last in the amp dtype, BatchNorm is folded,
+and the dense GEMM/conv/attention work goes to the ROCm libraries through PyTorch.  There is no CPU path: every
+kernel wrapper raises on a non-GPU tensor.
+"""
+from __future__ import annotations
+
+import math
+import os
+from typing import Dict, Optional
+from warnings import warn
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .transformer import Block, TransformerDecoder  # noqa: F401  (re-exported like the reference's module)
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def _round_up(n, m):
+    return (n + m - 1) // m * m
+
+
+def pixel_grid(b, h, w, device):
+    """(b,2,h,w) fp32 pixel centres (x,y) — Decoder.get_placeholder_flow, matcher.py:303-315."""
+    ys = torch.linspace(-1 + 1 / h, 1 - 1 / h, h, device=device)
+    xs = torch.linspace(-1 + 1 / w, 1 - 1 / w, w, device=device)
+    return torch.stack((xs[None, :].expand(h, w), ys[:, None].expand(h, w)), dim=0)[None].expand(b, 2, h, w).contiguous()
+
+
+def _params_version(module):
+    return tuple((p.data_ptr(), p._version) for p in list(module.parameters()) + list(module.buffers()))
+
+
+# ------------------------------------------------------------------------------------------------
+# ConvRefiner — matcher.py:17-143
+# ------------------------------------------------------------------------------------------------
+class ConvRefiner(nn.Module):
+    """x, warped y, displacement embedding and local correlation are assembled in ONE channels-last buffer
+    (pitch padded to 8 channels) by four kernels writing channel slices; every block is the fused
+    depthwise5x5+BN+ReLU kernel followed by a hipBLASLt GEMM for the 1x1 convolution."""
+
+    def __init__(self, in_dim, hidden_dim, out_dim, hidden_blocks, displacement_emb_dim, local_corr_radius=None,
+                 amp_dtype=torch.float16):
+        super().__init__()
+        assert in_dim == hidden_dim, "depthwise refiner blocks keep the channel count (all shipped models)"
+
+        def block(i, o):
+            return nn.Sequential(nn.Conv2d(i, o, 5, 1, 2, groups=i), nn.BatchNorm2d(o), nn.ReLU(inplace=True), nn.Conv2d(o, o, 1, 1, 0))
+
+        self.block1 = block(in_dim, hidden_dim)
+        self.hidden_blocks = nn.Sequential(*[block(hidden_dim, hidden_dim) for _ in range(hidden_blocks)])
+        self.out_conv = nn.Conv2d(hidden_dim, out_dim, 1, 1, 0)
+        self.disp_emb = nn.Conv2d(2, displacement_emb_dim, 1, 1, 0)
+        self.has_displacement_emb = True
+        self.local_corr_radius = local_corr_radius
+        self.in_dim, self.out_dim = in_dim, out_dim
+        self.amp_dtype = amp_dtype
+        self._prep = None
+
+    def prepare(self, dtype):
+        key = (dtype, _params_version(self))
+        if self._prep is not None and self._prep[0] == key:
+            return self._prep[1]
+        D = self.in_dim
+        Dp = _round_up(D, 8)
+        dev = self.out_conv.weight.device
+        blocks = []
+        for blk in [self.block1] + list(self.hidden_blocks):
+            dw, bn, _, pw = blk
+            s = bn.weight.float() / torch.sqrt(bn.running_var.float() + bn.eps)
+            w25 = torch.zeros(25, Dp, device=dev)
+            w25[:, :D] = dw.weight.float().reshape(D, 25).t()
+            scale = torch.zeros(Dp, device=dev)
+            shift = torch.zeros(Dp, device=dev)
+            scale[:D] = s
+            b_dw = dw.bias.float() if dw.bias is not None else torch.zeros(D, device=dev)
+            shift[:D] = (b_dw - bn.running_mean.float()) * s + bn.bias.float()
+            wt = torch.zeros(Dp, Dp, device=dev)
+            wt[:D, :D] = pw.weight.float().reshape(D, D).t()            # (in, out): X @ wt
+            b = torch.zeros(Dp, device=dev)
+            b[:D] = pw.bias.float()
+            blocks.append((w25.contiguous(), scale, shift, wt.to(dtype).contiguous(), b.to(dtype)))
+        wo = torch.zeros(Dp, self.out_dim, device=dev)
+        wo[:D] = self.out_conv.weight.float().reshape(self.out_dim, D).t()
+        prep = dict(D=D, Dp=Dp, blocks=blocks, wo=wo.contiguous(), bo=self.out_conv.bias.float(),
+                    we=self.disp_emb.weight.float().reshape(-1, 2).contiguous(), be=self.disp_emb.bias.float())
+        self._prep = (key, prep)
+        return prep
+
+    @torch.no_grad()
+    def forward(self, x, y, flow, scale_factor=1, logits=None, dtype=None):
+        """x, y: (B,C,h,w) features; flow (B,2,h,w) fp32.  Returns (delta_flow (B,2,h,w), delta_certainty (B,1,h,w)) fp32
+        — matcher.py:105-143."""
+        dtype = dtype or self.amp_dtype
+        P = self.prepare(dtype)
+        B, C, h, w = x.shape
+        D, Dp = P["D"], P["Dp"]
+        E = P["we"].shape[0]
+        r = self.local_corr_radius
+        K = (2 * r + 1) ** 2 if r else 0
+        assert 2 * C + E + K == D, "feature width does not match this refiner"
+        flow = flow.float().contiguous()
+        buf = torch.empty((B, h, w, Dp), dtype=dtype, device=x.device)
+        d = buf.permute(0, 3, 1, 2)
+        d[:, :C].copy_(x)
+        if Dp > D:
+            buf[..., D:].zero_()
+        yy = y.to(dtype)
+        ops.warp_bilinear(yy, flow, out=d[:, C:2 * C])                                        # matcher.py:109
+        ops.disp_emb(flow, P["we"], P["be"], 40 / 32 * scale_factor, out=d[:, 2 * C:2 * C + E])  # :111-120
+        if r:
+            ops.local_correlation(d[:, :C], yy, r, flow=flow, out=d[:, 2 * C + E:D])           # :121-125
+        M = B * h * w
+        cur = buf
+        for (w25, scale, shift, wt, b) in P["blocks"]:                                         # :139-140
+            t = ops.dwconv5x5_bn_relu(cur.permute(0, 3, 1, 2), w25, scale, shift)
+            cur = torch.addmm(b, t.permute(0, 2, 3, 1).reshape(M, Dp), wt).view(B, h, w, Dp)
+        out = torch.addmm(P["bo"], cur.reshape(M, Dp).float(), P["wo"])                        # out_conv in fp32, :141
+        out = out.view(B, h, w, self.out_dim).permute(0, 3, 1, 2).contiguous()
+        return out[:, :-1], out[:, -1:]
+
+
+# ------------------------------------------------------------------------------------------------
+# GP with the cosine kernel — matcher.py:145-273
+# ------------------------------------------------------------------------------------------------
+class CosKernel(nn.Module):
+    def __init__(self, T=0.2, learn_temperature=False):
+        super().__init__()
+        self.T = T
+
+    def __call__(self, x, y, eps=1e-6):
+        return ops.cos_kernel(x, y, T=self.T, eps=eps)
+
+
+class GP(nn.Module):
+    """Posterior mean of the Fourier positional basis (no_cov=True, the shipped configuration).  The two kernel
+    matrices come from the fp32-MFMA CosKernel kernel; `inv(K_yy + sigma I) @ f` (matcher.py:259-263) is solved by
+    Cholesky (K_yy + sigma I is SPD) instead of forming the inverse; the dead K_xx (matcher.py:255) is skipped."""
+
+    def __init__(self, gp_dim=512, T=0.2, sigma_noise=0.1, kernel=None, **_):
+        super().__init__()
+        self.K = CosKernel(T=T)
+        self.sigma_noise = sigma_noise
+        self.pos_conv = nn.Conv2d(2, gp_dim, 1, 1)
+        self.dim = gp_dim
+        self._basis = {}
+
+    def basis(self, b, h, w, device):
+        key = (h, w, device, _params_version(self.pos_conv))
+        f = self._basis.get(key)
+        if f is None:
+            g = pixel_grid(1, h, w, device)
+            f = torch.cos(8 * math.pi * F.conv2d(g, self.pos_conv.weight.float(), self.pos_conv.bias.float()))   # :222-247
+            f = f.flatten(2).transpose(1, 2).contiguous()
+            self._basis = {key: f}
+        return f.expand(b, -1, -1)
+
+    @torch.no_grad()
+    def forward(self, x, y, **kwargs):
+        b, c, h1, w1 = x.shape
+        _, _, h2, w2 = y.shape
+        xs = x.float().flatten(2).transpose(1, 2).contiguous()
+        ys = y.float().flatten(2).transpose(1, 2).contiguous()
+        K_yy = ops.cos_kernel(ys, ys, T=self.K.T, diag_add=self.sigma_noise)
+        K_xy = ops.cos_kernel(xs, ys, T=self.K.T)
+        L = torch.linalg.cholesky(K_yy)
+        mu = K_xy @ torch.cholesky_solve(self.basis(b, h2, w2, x.device), L)
+        return mu.transpose(1, 2).reshape(b, self.dim, h1, w1)
+
+    def posterior_rows(self, xs, ys, h2, w2):
+        """Token-major variant used by the Decoder: xs, ys (B,N,D) fp32 -> mu (B,N,gp_dim) fp32."""
+        K_yy = ops.cos_kernel(ys, ys, T=self.K.T, diag_add=self.sigma_noise)
+        K_xy = ops.cos_kernel(xs, ys, T=self.K.T)
+        L = torch.linalg.cholesky(K_yy)
+        return K_xy @ torch.cholesky_solve(self.basis(xs.shape[0], h2, w2, xs.device), L)
+
+
+# ------------------------------------------------------------------------------------------------
+# Decoder — matcher.py:275-422
+# ------------------------------------------------------------------------------------------------
+class Decoder(nn.Module):
+    def __init__(self, embedding_decoder, gps, proj, conv_refiner, detach=True, scales=("16", "8", "4", "2", "1"),
+                 amp_dtype=torch.float16, **_):
+        super().__init__()
+        self.embedding_decoder, self.gps, self.proj, self.conv_refiner = embedding_decoder, gps, proj, conv_refiner
+        self.scales = list(scales)
+        self.refine_init = 4
+        self.amp_dtype = amp_dtype
+        self._proj = None
+
+    def get_placeholder_flow(self, b, h, w, device):
+        return pixel_grid(b, h, w, device)
+
+    def folded_proj(self, dtype):
+        key = (dtype, _params_version(self.proj))
+        if self._proj is not None and self._proj[0] == key:
+            return self._proj[1]
+        out = {}
+        for s, seq in self.proj.items():
+            conv, bn = seq[0], seq[1]
+            g = bn.weight.float() / torch.sqrt(bn.running_var.float() + bn.eps)
+            wt = (conv.weight.float().reshape(conv.out_channels, -1) * g[:, None]).t().contiguous().to(dtype)   # (in,out)
+            b = ((conv.bias.float() - bn.running_mean.float()) * g + bn.bias.float()).to(dtype)
+            out[s] = (wt, b)
+        self._proj = (key, out)
+        return out
+
+    def project(self, s, f, dtype):
+        """1x1 conv + BN(eval) as one GEMM over the channels-last rows — matcher.py:366-371."""
+        wt, b = self.folded_proj(dtype)[s]
+        B, C, h, w = f.shape
+        rows = f.to(dtype).permute(0, 2, 3, 1).reshape(B * h * w, C)
+        return torch.addmm(b, rows, wt).view(B, h, w, -1).permute(0, 3, 1, 2)
+
+    @torch.no_grad()
+    def forward(self, f1, f2, gt_warp=None, gt_prob=None, upsample=False, flow=None, certainty=None, scale_factor=1,
+                swapped_pair=False):
+        """Coarse-to-fine loop.  `swapped_pair=True` tells the decoder that f2 is f1 with its two batch halves swapped
+        (forward_symmetric), so each level is projected once."""
+        dtype = self.amp_dtype
+        all_scales = self.scales if not upsample else ["8", "4", "2", "1"]                    # matcher.py:335
+        sizes = {s: tuple(f1[s].shape[-2:]) for s in f1}
+        h, w = sizes[1]
+        b = f1[1].shape[0]
+        device = f1[1].device
+        first = int(all_scales[0])
+        if not upsample:
+            flow = pixel_grid(b, *sizes[first], device)                                      # :346
+            certainty = None                                                                 # the reference's 0.0
+        else:
+            flow = ops.interp_bilinear(flow, sizes[first])                                   # :349-360
+            certainty = ops.interp_bilinear(certainty, sizes[first])
+        corresps = {}
+        for s in all_scales:
+            ins = int(s)
+            corresps[ins] = {}
+            x = self.project(s, f1[ins], dtype)
+            if swapped_pair:
+                y = torch.cat((x[b // 2:], x[:b // 2]), dim=0)
+            else:
+                y = self.project(s, f2[ins], dtype)
+            hs, ws = sizes[ins]
+            if ins in self.embedding_decoder.scales():
+                xs = x.permute(0, 2, 3, 1).reshape(b, hs * ws, -1)
+                ys = y.permute(0, 2, 3, 1).reshape(b, hs * ws, -1)
+                mu = self.gps[s].posterior_rows(xs.float().contiguous(), ys.float().contiguous(), hs, ws)   # :377
+                tokens = torch.cat((mu.to(dtype), xs), dim=2)                                 # transformer/__init__.py:35-41
+                rows = self.embedding_decoder.forward_rows(tokens)                            # (b, hw, 4097)
+                flow, certainty = ops.cls_rows_to_flow(rows, b, hs, ws)                       # :378-385
+            delta, dcert = self.conv_refiner[s](x, y, flow, scale_factor=scale_factor, logits=certainty, dtype=dtype)   # :393
+            flow = flow + ins * torch.stack((delta[:, 0] / (self.refine_init * w), delta[:, 1] / (self.refine_init * h)), dim=1)
+            certainty = dcert if certainty is None else certainty + dcert                     # :397-402
+            corresps[ins].update({"certainty": certainty, "flow": flow})
+            if s != "1":
+                flow = ops.interp_bilinear(flow, sizes[ins // 2])                             # :408-417
+                certainty = ops.interp_bilinear(certainty, sizes[ins // 2])
+        return corresps
+
+
+# ------------------------------------------------------------------------------------------------
+# RegressionMatcher — matcher.py:425-766
+# ------------------------------------------------------------------------------------------------
+def _check_rgb(im):
+    if im.mode != "RGB":
+        raise NotImplementedError("Can't handle non-RGB images")                              # utils.py:660-662
+
+
+def _check_not_i16(im):
+    if im.mode == "I;16":
+        raise NotImplementedError("Can't handle 16 bit images")                               # utils.py:656-658
+
+
+def preprocess(im, size):
+    """PIL RGB -> PIL bicubic resize to (h,w) -> /255 -> ImageNet normalise -> (3,h,w) fp32 (utils.py:165-261)."""
+    from PIL import Image
+    h, w = size
+    a = np.array(im.resize((w, h), Image.BICUBIC), dtype=np.float32).transpose(2, 0, 1) / 255.0
+    t = torch.from_numpy(a)
+    return (t - torch.tensor(IMAGENET_MEAN)[:, None, None]) / torch.tensor(IMAGENET_STD)[:, None, None]
+
+
+class RegressionMatcher(nn.Module):
+    def __init__(self, encoder, decoder, h=448, w=448, sample_mode="threshold_balanced", upsample_preds=False,
+                 symmetric=False, name=None, attenuate_cert=None):
+        super().__init__()
+        self.attenuate_cert = attenuate_cert
+        self.encoder, self.decoder = encoder, decoder
+        self.name = name
+        self.w_resized, self.h_resized = w, h
+        self.sample_mode = sample_mode
+        self.upsample_preds = upsample_preds
+        self.upsample_res = (14 * 16 * 6, 14 * 16 * 6)
+        self.symmetric = symmetric
+        self.sample_thresh = 0.05
+
+    def get_output_resolution(self):
+        return self.upsample_res if self.upsample_preds else (self.h_resized, self.w_resized)
+
+    def extract_backbone_features(self, batch, batched=True, upsample=False):
+        if batched:
+            return self.encoder(torch.cat((batch["im_A"], batch["im_B"]), dim=0), upsample=upsample)
+        return self.encoder(batch["im_A"], upsample=upsample), self.encoder(batch["im_B"], upsample=upsample)
+
+    def forward(self, batch, batched=True, upsample=False, scale_factor=1):
+        pyr = self.extract_backbone_features(batch, batched=batched, upsample=upsample)
+        if batched:
+            f_q = {s: f.chunk(2)[0] for s, f in pyr.items()}
+            f_s = {s: f.chunk(2)[1] for s, f in pyr.items()}
+        else:
+            f_q, f_s = pyr
+        return self.decoder(f_q, f_s, upsample=upsample, scale_factor=scale_factor, **(batch.get("corresps") or {}))
+
+    def forward_symmetric(self, batch, batched=True, upsample=False, scale_factor=1):
+        pyr = self.extract_backbone_features(batch, batched=batched, upsample=upsample)       # matcher.py:516-528
+        kw = {k: v for k, v in (batch.get("corresps") or {}).items() if k in ("flow", "certainty")}
+        return self.decoder(pyr, None, upsample=upsample, scale_factor=scale_factor, swapped_pair=True, **kw)
+
+    # -- sampling --------------------------------------------------------------------------------
+    def sample(self, matches, certainty, num=10000):
+        """matcher.py:468-495: certainty-thresholded multinomial draw, then KDE-balanced re-draw (fused HIP KDE)."""
+        if "threshold" in self.sample_mode:
+            certainty = certainty.clone()
+            certainty[certainty > self.sample_thresh] = 1
+        matches, certainty = matches.reshape(-1, 4), certainty.reshape(-1)
+        expansion = 4 if "balanced" in self.sample_mode else 1
+        good = torch.multinomial(certainty, num_samples=min(expansion * num, len(certainty)), replacement=False)
+        good_matches, good_certainty = matches[good], certainty[good]
+        if "balanced" not in self.sample_mode:
+            return good_matches, good_certainty
+        density = ops.kde(good_matches, std=0.1)
+        p = 1 / (density + 1)
+        p[density < 10] = 1e-7
+        bal = torch.multinomial(p.float(), num_samples=min(num, len(good_certainty)), replacement=False)
+        return good_matches[bal], good_certainty[bal]
+
+    # -- coordinates -----------------------------------------------------------------------------
+    def to_pixel_coordinates(self, coords, H_A, W_A, H_B=None, W_B=None):
+        if coords.shape[-1] == 2:
+            return self._to_pixel_coordinates(coords, H_A, W_A)
+        if isinstance(coords, (list, tuple)):
+            kA, kB = coords[0], coords[1]
+        else:
+            kA, kB = coords[..., :2], coords[..., 2:]
+        return self._to_pixel_coordinates(kA, H_A, W_A), self._to_pixel_coordinates(kB, H_B, W_B)
+
+    def _to_pixel_coordinates(self, coords, H, W):
+        return torch.stack((W / 2 * (coords[..., 0] + 1), H / 2 * (coords[..., 1] + 1)), axis=-1)
+
+    def to_normalized_coordinates(self, coords, H_A, W_A, H_B, W_B):
+        if isinstance(coords, (list, tuple)):
+            kA, kB = coords[0], coords[1]
+        else:
+            kA, kB = coords[..., :2], coords[..., 2:]
+        kA = torch.stack((2 / W_A * kA[..., 0] - 1, 2 / H_A * kA[..., 1] - 1), axis=-1)
+        kB = torch.stack((2 / W_B * kB[..., 0] - 1, 2 / H_B * kB[..., 1] - 1), axis=-1)
+        return kA, kB
+
+    def match_keypoints(self, x_A, x_B, warp, certainty, return_tuple=True, return_inds=False):
+        """matcher.py:576-591: warp the A keypoints, mutual nearest neighbours among x_B, certainty gate."""
+        x_A_to_B = F.grid_sample(warp[..., -2:].permute(2, 0, 1)[None], x_A[None, None], align_corners=False, mode="bilinear")[0, :, 0].mT
+        cert = F.grid_sample(certainty[None, None, ...], x_A[None, None], align_corners=False, mode="bilinear")[0, 0, 0]
+        Dm = torch.cdist(x_A_to_B, x_B)
+        iA, iB = torch.nonzero((Dm == Dm.min(dim=-1, keepdim=True).values) * (Dm == Dm.min(dim=-2, keepdim=True).values)
+                               * (cert[:, None] > self.sample_thresh), as_tuple=True)
+        if return_tuple:
+            return (iA, iB) if return_inds else (x_A[iA], x_B[iB])
+        return torch.cat((iA, iB), dim=-1) if return_inds else torch.cat((x_A[iA], x_B[iB]), dim=-1)
+
+    # -- match -----------------------------------------------------------------------------------
+    @torch.inference_mode()
+    def match_tensors(self, A_lo, B_lo, A_hi=None, B_hi=None):
+        """P pairs at once.  A_lo,B_lo: (P,3,h,w) normalised coarse images; A_hi,B_hi: (P,3,H,W) for the upsample
+        pass.  Returns the stack of per-pair results: warp (P,H,2W,4), certainty (P,H,2W) (symmetric) — the batched
+        560->864 semantics the reference leaves undefined (its batched+upsample path raises)."""
+        symmetric = self.symmetric
+        batch = {"im_A": A_lo, "im_B": B_lo}
+        corresps = self.forward_symmetric(batch) if symmetric else self.forward(batch, batched=True)
+        hs, ws = A_lo.shape[-2:]
+        cert16 = corresps[16]["certainty"] if self.attenuate_cert else None
+        if self.upsample_preds:
+            if A_hi is None or B_hi is None:
+                raise ValueError("upsample_preds=True needs the high-resolution images (A_hi, B_hi)")
+            hs, ws = A_hi.shape[-2:]
+            scale_factor = math.sqrt(hs * ws / (A_lo.shape[-2] * A_lo.shape[-1]))            # matcher.py:677
+            batch = {"im_A": A_hi, "im_B": B_hi, "corresps": corresps[1]}
+            corresps = (self.forward_symmetric(batch, upsample=True, scale_factor=scale_factor) if symmetric
+                        else self.forward(batch, batched=True, upsample=True, scale_factor=scale_factor))
+        return ops.match_finalize(corresps[1]["flow"], corresps[1]["certainty"], cert16, symmetric=symmetric)
+
+    @torch.inference_mode()
+    def match(self, im_A_input, im_B_input, *args, batched=False, device=None, im_A_hi=None, im_B_hi=None):
+        """matcher.py:593-730.  Paths or RGB PIL images (one pair) -> warp (H,2W,4), certainty (H,2W); extra positional
+        arguments are ignored like the reference does.  batched=True takes normalised tensors (plus im_A_hi/im_B_hi
+        when upsample_preds) and returns the stacked per-pair results."""
+        from PIL import Image
+        if device is None:
+            device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("roma_amd runs on an MI355X only; there is no CPU path (use the oracle for CPU numbers)")
+        self.train(False)
+        if batched:
+            b, c, h, w = im_A_input.shape
+            b2, c2, h2, w2 = im_B_input.shape
+            assert w == w2 and h == h2, "For batched images we assume same size"
+            if h != self.h_resized or self.w_resized != w:
+                warn("Model resolution and batch resolution differ, may produce unexpected results")
+            hi = (None, None) if im_A_hi is None else (im_A_hi.to(device), im_B_hi.to(device))
+            return self.match_tensors(im_A_input.to(device), im_B_input.to(device), *hi)
+        ims = []
+        for im in (im_A_input, im_B_input):
+            if isinstance(im, (str, os.PathLike)):
+                im = Image.open(im)
+                _check_not_i16(im)
+                im = im.convert("RGB")
+            else:
+                _check_rgb(im)
+            ims.append(im)
+        lo = [preprocess(im, (self.h_resized, self.w_resized))[None].to(device) for im in ims]
+        hi = [preprocess(im, self.upsample_res)[None].to(device) for im in ims] if self.upsample_preds else [None, None]
+        warp, cert = self.match_tensors(lo[0], lo[1], hi[0], hi[1])
+        return warp[0], cert[0]
+
+    def visualize_warp(self, warp, certainty, im_A=None, im_B=None, im_A_path=None, im_B_path=None, device="cuda",
+                       symmetric=True, save_path=None, unnormalize=False):
+        """matcher.py:732-766 (host-side visualisation helper; not on the timed path)."""
+        from PIL import Image
+        H, W2, _ = warp.shape
+        W = W2 // 2 if symmetric else W2
+        if im_A is None:
+            im_A, im_B = Image.open(im_A_path).convert("RGB"), Image.open(im_B_path).convert("RGB")
+        if not isinstance(im_A, torch.Tensor):
+            im_A, im_B = im_A.resize((W, H)), im_B.resize((W, H))
+            x_B = (torch.tensor(np.array(im_B)) / 255).to(device).permute(2, 0, 1)
+            x_A = (torch.tensor(np.array(im_A)) / 255).to(device).permute(2, 0, 1)
+        else:
+            x_A, x_B = im_A, im_B
+        a2b = F.grid_sample(x_B[None], warp[:, :W, 2:][None], mode="bilinear", align_corners=False)[0]
+        if symmetric:
+            b2a = F.grid_sample(x_A[None], warp[:, W:, :2][None], mode="bilinear", align_corners=False)[0]
+            warp_im = torch.cat((a2b, b2a), dim=2)
+        else:
+            warp_im = a2b
+        white = torch.ones((H, W2 if symmetric else W), device=device)
+        vis = certainty * warp_im + (1 - certainty) * white
+        if save_path is not None:
+            arr = (vis.permute(1, 2, 0).clamp(0, 1).cpu().numpy() * 255).astype(np.uint8)
+            Image.fromarray(arr).save(save_path)
+        return vis

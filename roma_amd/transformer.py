@@ -1,0 +1,136 @@
+"""Transformer pieces of the hot path on PyTorch-ROCm library kernels (hipBLASLt GEMMs, fused SDPA).
+
+Module/parameter names follow the reference so its checkpoints load unchanged:
+`Block` = romatch/models/transformer/layers/block.py:36-107 (pre-LN, optional LayerScale),
+`TransformerDecoder` = romatch/models/transformer/__init__.py:10-46, `DinoViT` = transformer/dinov2.py:43-237 (vit_large).
+These are dense GEMM/attention work that the north star leaves to the vendor libraries; the hand-written HIP kernels
+start where the decoder's logits are consumed (ops.cls_rows_to_flow).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, num_heads, qkv_bias):
+        super().__init__()
+        self.num_heads = num_heads
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+
+    def forward(self, x):
+        B, N, C = x.shape
+        qkv = self.qkv(x).view(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4)
+        o = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2])          # scale = head_dim^-0.5, as attention.py:53-56
+        return self.proj(o.transpose(1, 2).reshape(B, N, C))
+
+
+class Mlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+    def forward(self, x):
+        return self.fc2(F.gelu(self.fc1(x)))
+
+
+class LayerScale(nn.Module):
+    def __init__(self, dim, init=1.0):
+        super().__init__()
+        self.gamma = nn.Parameter(init * torch.ones(dim))
+
+    def forward(self, x):
+        return x * self.gamma
+
+
+class Block(nn.Module):
+    def __init__(self, dim, num_heads, qkv_bias=False, init_values=None, ln_eps=1e-5):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=ln_eps)
+        self.attn = Attention(dim, num_heads, qkv_bias)
+        self.ls1 = LayerScale(dim, init_values) if init_values else nn.Identity()
+        self.norm2 = nn.LayerNorm(dim, eps=ln_eps)
+        self.mlp = Mlp(dim, int(dim * 4.0))
+        self.ls2 = LayerScale(dim, init_values) if init_values else nn.Identity()
+
+    def forward(self, x):
+        x = x + self.ls1(self.attn(self.norm1(x)))
+        return x + self.ls2(self.mlp(self.norm2(x)))
+
+
+class TransformerDecoder(nn.Module):
+    """Returns the token-major logit rows (B, H*W, out_dim) — the (B,out_dim,H,W) permute of the reference
+    (transformer/__init__.py:44) is folded into the consumer kernel's strides."""
+
+    def __init__(self, blocks, hidden_dim, out_dim, is_classifier=True):
+        super().__init__()
+        self.blocks = blocks
+        self.to_out = nn.Linear(hidden_dim, out_dim)
+        self.hidden_dim, self.out_dim, self.is_classifier = hidden_dim, out_dim, is_classifier
+        self._scales = [16]
+
+    def scales(self):
+        return self._scales.copy()
+
+    def forward_rows(self, tokens):
+        return self.to_out(self.blocks(tokens))
+
+
+class PatchEmbed(nn.Module):
+    def __init__(self, patch, dim):
+        super().__init__()
+        self.proj = nn.Conv2d(3, dim, patch, patch)
+
+    def forward(self, x):
+        return self.proj(x).flatten(2).transpose(1, 2)
+
+
+class DinoViT(nn.Module):
+    """DINOv2 ViT-L/14 trunk: LN eps 1e-6, qkv bias, LayerScale; returns the normalised patch tokens."""
+
+    def __init__(self, img_size=518, patch_size=14, dim=1024, depth=24, heads=16, init_values=1.0):
+        super().__init__()
+        self.patch_size = patch_size
+        n = (img_size // patch_size) ** 2
+        self.patch_embed = PatchEmbed(patch_size, dim)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, n + 1, dim))
+        self.mask_token = nn.Parameter(torch.zeros(1, dim))
+        self.blocks = nn.ModuleList([Block(dim, heads, qkv_bias=True, init_values=init_values, ln_eps=1e-6) for _ in range(depth)])
+        self.norm = nn.LayerNorm(dim, eps=1e-6)
+        self._pos_cache = {}
+
+    def pos_encoding(self, w, h, dtype):
+        """dinov2.py:166-190: bicubic resize of the 37x37 table with scale_factor (w0+0.1)/37; cached per input size."""
+        key = (w, h, dtype, self.pos_embed.device, self.pos_embed._version)
+        hit = self._pos_cache.get(key)
+        if hit is not None:
+            return hit
+        N = self.pos_embed.shape[1] - 1
+        w0, h0 = w // self.patch_size, h // self.patch_size
+        if w0 * h0 == N and w == h:
+            pe = self.pos_embed
+        else:
+            p = self.pos_embed.float()
+            dim = p.shape[-1]
+            side = int(math.sqrt(N))
+            grid = F.interpolate(p[:, 1:].reshape(1, side, side, dim).permute(0, 3, 1, 2),
+                                 scale_factor=((w0 + 0.1) / math.sqrt(N), (h0 + 0.1) / math.sqrt(N)), mode="bicubic")
+            assert grid.shape[-2] == w0 and grid.shape[-1] == h0
+            pe = torch.cat((p[:, :1], grid.permute(0, 2, 3, 1).reshape(1, -1, dim)), dim=1)
+        pe = pe.to(dtype)
+        self._pos_cache = {key: pe}
+        return pe
+
+    def patch_tokens(self, x):
+        B, _, w, h = x.shape
+        t = self.patch_embed(x)
+        t = torch.cat((self.cls_token.expand(B, -1, -1), t), dim=1) + self.pos_encoding(w, h, t.dtype)
+        for blk in self.blocks:
+            t = blk(t)
+        return self.norm(t)[:, 1:]

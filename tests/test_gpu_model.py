@@ -1,0 +1,176 @@
+"""Model-level parity on the GPU: the product modules (roma_amd.matcher, HIP kernels + ROCm library GEMMs) against
+the reference's golden vectors and against the CPU oracle, with the SAME recipe weights loaded through the
+reference's state-dict key layout.  fp32 mode is the parity mode (bar: 1e-3 max-abs on warp/certainty, BASELINE.json);
+fp16 mode (the reference's GPU semantics) is checked for the bulk of the pixels, because the decoder's arg-max over 4096
+classes is a hard discontinuity (hard parts)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as H
+from tests.golden import cases, recipes as R
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+DEV = "cuda"
+
+
+def maxerr(a, b):
+    return float((a.detach().float().cpu() - b.detach().float().cpu()).abs().max())
+
+
+def _M():
+    import roma_amd.matcher as M
+    return M
+
+
+@pytest.mark.parametrize("name", list(cases.REFINER_CASES))
+def test_conv_refiner_golden(name):
+    g = H.golden("conv_refiner")
+    m = H.load_recipe_weights(H.build_refiner(_M(), name), f"ref.{name}.").to(DEV)
+    x, y, flow, sf = cases.refiner_inputs(name)
+    d, c = m(H.T(x, DEV), H.T(y, DEV), H.T(flow, DEV), scale_factor=sf, dtype=torch.float32)
+    assert maxerr(d, H.T(g[f"{name}_dflow"])) < 5e-5
+    assert maxerr(c, H.T(g[f"{name}_dcert"])) < 5e-5
+
+
+def test_gp_golden():
+    g = H.golden("gp")
+    for name, (b, c, h, w, d) in {"small": (1, 512, 10, 10, 512), "rect": (2, 64, 6, 9, 32)}.items():
+        gp = H.load_recipe_weights(_M().GP(d), f"gp.{name}.", gains={"pos_conv": 4.0}).to(DEV)
+        mu = gp(H.T(R.normal(f"gp.{name}.x", (b, c, h, w)), DEV), H.T(R.normal(f"gp.{name}.y", (b, c, h, w)), DEV))
+        assert maxerr(mu, H.T(g[f"{name}_mu"])) < 2e-5
+
+
+def test_decoder_both_modes_golden():
+    g = H.golden("decoder")
+    dec = H.load_recipe_weights(H.build_reduced_decoder(_M()), "dec.", gains=cases.DEC_GAINS).to(DEV)
+    dec.amp_dtype = torch.float32
+    f1, f2 = cases.decoder_pyramids("coarse", 2, 112, upsample=False)
+    c = dec({s: H.T(v, DEV) for s, v in f1.items()}, {s: H.T(v, DEV) for s, v in f2.items()})
+    for s in (16, 8, 4, 2, 1):
+        assert maxerr(c[s]["flow"], H.T(g[f"coarse_flow_{s}"])) < 2e-5, s
+        assert maxerr(c[s]["certainty"], H.T(g[f"coarse_cert_{s}"])) < 2e-4, s
+    g1, g2 = cases.decoder_pyramids("up", 2, 176, upsample=True)
+    u = dec({s: H.T(v, DEV) for s, v in g1.items()}, {s: H.T(v, DEV) for s, v in g2.items()}, upsample=True,
+            flow=c[1]["flow"], certainty=c[1]["certainty"], scale_factor=math.sqrt(176 * 176 / (112 * 112)))
+    for s in (8, 4, 2, 1):
+        assert maxerr(u[s]["flow"], H.T(g[f"up_flow_{s}"])) < 2e-5, s
+        assert maxerr(u[s]["certainty"], H.T(g[f"up_cert_{s}"])) < 2e-4, s
+
+
+@pytest.fixture(scope="module")
+def full_model():
+    from roma_amd.model_zoo import build_roma
+    m = build_roma((112, 112), upsample_preds=True, amp_dtype=torch.float32)
+    vit = m.encoder.dinov2_vitl14[0]
+    w, v = H.full_model_weights({k: tuple(t.shape) for k, t in m.state_dict().items()},
+                                {k: tuple(t.shape) for k, t in vit.state_dict().items()})
+    m.load_state_dict({k: H.T(a) for k, a in w.items()})
+    vit.load_state_dict({k: H.T(a) for k, a in v.items()})
+    m.upsample_res = (168, 168)
+    return m.to(DEV).eval()
+
+
+def _set_dtype(m, dt):
+    m.encoder.amp_dtype = dt
+    m.decoder.amp_dtype = dt
+    for r in m.decoder.conv_refiner.values():
+        r.amp_dtype = dt
+
+
+def test_end_to_end_reduced_fp32_vs_reference_golden(full_model):
+    """The shipped architecture (ViT-L/14 + VGG19-BN + full decoder), sacre_coeur pair, 112->168, fp32 mode."""
+    g = H.golden("e2e_112")
+    _set_dtype(full_model, torch.float32)
+    warp, cert = full_model.match(H.asset("sacre_coeur_A.jpg"), H.asset("sacre_coeur_B.jpg"), device=DEV)
+    assert warp.shape == (168, 336, 4) and cert.shape == (168, 336) and warp.dtype == torch.float32
+    dw = (warp.cpu() - H.T(g["r112_warp"])).abs()
+    dc = (cert.cpu() - H.T(g["r112_cert"])).abs()
+    frac = float((dw > 1e-3).float().mean())
+    print(f"fp32 e2e: warp max {float(dw.max()):.2e} cert max {float(dc.max()):.2e} frac>1e-3 {frac:.2e}")
+    assert float(dw.max()) < 1e-3 and float(dc.max()) < 1e-3
+
+
+def test_end_to_end_560_coarse_only_fp32(full_model):
+    g = H.golden("e2e_560")
+    _set_dtype(full_model, torch.float32)
+    full_model.h_resized = full_model.w_resized = 560
+    full_model.upsample_preds = False
+    try:
+        warp, cert = full_model.match(H.asset("sacre_coeur_A.jpg"), H.asset("sacre_coeur_B.jpg"), device=DEV)
+    finally:
+        full_model.h_resized = full_model.w_resized = 112
+        full_model.upsample_preds = True
+    dw = (warp.cpu()[::8, ::8] - H.T(g["c560_warp_sample"])).abs()
+    dc = (cert.cpu()[::8, ::8] - H.T(g["c560_cert_sample"])).abs()
+    frac = float((dw > 1e-3).float().mean())
+    print(f"560 coarse fp32: warp max {float(dw.max()):.2e} cert max {float(dc.max()):.2e} frac>1e-3 {frac:.2e}")
+    assert frac < 2e-3 and float(dc.max()) < 2e-3
+
+
+def test_end_to_end_fp16_mode_bulk_agreement(full_model):
+    g = H.golden("e2e_112")
+    _set_dtype(full_model, torch.float16)
+    try:
+        warp, cert = full_model.match(H.asset("sacre_coeur_A.jpg"), H.asset("sacre_coeur_B.jpg"), device=DEV)
+    finally:
+        _set_dtype(full_model, torch.float32)
+    assert torch.isfinite(warp).all() and torch.isfinite(cert).all()
+    dw = (warp.cpu() - H.T(g["r112_warp"])).abs()
+    dc = (cert.cpu() - H.T(g["r112_cert"])).abs()
+    print(f"fp16 e2e: warp median {float(dw.median()):.2e} p99 {float(dw.flatten().kthvalue(int(dw.numel()*0.99)).values):.2e} "
+          f"max {float(dw.max()):.2e}; cert max {float(dc.max()):.2e}")
+    assert float(dw.median()) < 5e-3 and float(dc.median()) < 5e-3
+
+
+def test_batched_pairs_equal_per_pair_results(full_model):
+    """Stack-of-per-pair semantics: P=2 pairs in one call == each pair alone (bit for bit in fp32)."""
+    _set_dtype(full_model, torch.float32)
+    gen = torch.Generator().manual_seed(5)
+    lo = torch.randn(2, 2, 3, 112, 112, generator=gen).to(DEV)
+    hi = torch.randn(2, 2, 3, 168, 168, generator=gen).to(DEV)
+    w2, c2 = full_model.match_tensors(lo[0], lo[1], hi[0], hi[1])
+    for i in range(2):
+        w1, c1 = full_model.match_tensors(lo[0, i:i + 1], lo[1, i:i + 1], hi[0, i:i + 1], hi[1, i:i + 1])
+        assert maxerr(w2[i], w1[0]) < 1e-4 and maxerr(c2[i], c1[0]) < 1e-4
+
+
+def test_sample_and_coordinates(full_model):
+    _set_dtype(full_model, torch.float32)
+    warp, cert = full_model.match(H.asset("sacre_coeur_A.jpg"), H.asset("sacre_coeur_B.jpg"), device=DEV)
+    torch.manual_seed(0)
+    m, c = full_model.sample(warp, cert, num=500)
+    assert m.shape == (500, 4) and c.shape == (500,)
+    assert float(m.abs().max()) <= 1.0
+    kA, kB = full_model.to_pixel_coordinates(m, 480, 640, 640, 618)
+    assert kA.shape == (500, 2) and float(kA[:, 0].max()) <= 640 and float(kB[:, 1].max()) <= 640
+    nA, nB = full_model.to_normalized_coordinates((kA, kB), 480, 640, 640, 618)
+    assert maxerr(nA, m[:, :2]) < 1e-5 and maxerr(nB, m[:, 2:]) < 1e-5
+    assert full_model.get_output_resolution() == (168, 168)
+
+
+def test_match_rejects_bad_images(full_model):
+    from PIL import Image
+    with pytest.raises(NotImplementedError):
+        full_model.match(Image.new("L", (32, 32)), Image.new("L", (32, 32)), device=DEV)
+    with pytest.raises(RuntimeError):
+        full_model.match(H.asset("sacre_coeur_A.jpg"), H.asset("sacre_coeur_B.jpg"), device="cpu")
+
+
+def test_tiny_roma_forward_and_match_golden():
+    from roma_amd.tiny import TinyRoMa
+    g = H.golden("tiny")
+    xf = H.load_recipe_weights(cases.StubXFeat(), "tiny.xfeat.")
+    m = TinyRoMa(xf.eval(), freeze_xfeat=True, exact_softmax=False)
+    H.load_recipe_weights(m, "tiny.")
+    m = m.to(DEV).eval()
+    im0, im1 = H.T(R.uniform("tiny.im0", (1, 3, 100, 140), 0, 1), DEV), H.T(R.uniform("tiny.im1", (1, 3, 100, 140), 0, 1), DEV)
+    c = m({"im_A": im0, "im_B": im1})
+    for s in (8, 4):
+        assert maxerr(c[s]["flow"], H.T(g[f"fwd_flow_{s}"])) < 2e-4
+        assert maxerr(c[s]["certainty"], H.T(g[f"fwd_cert_{s}"])) < 2e-4
+    warp, cert = m.match(im0, im1)
+    assert maxerr(warp, H.T(g["match_warp"])) < 2e-4 and maxerr(cert, H.T(g["match_cert"])) < 2e-4

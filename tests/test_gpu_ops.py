@@ -210,7 +210,8 @@ def test_cos_kernel_full_size_asymmetric_and_diag():
     y = H.T(R.normal("cosfull.y", (2, 1600, 512))) * H.T(R.uniform("cosfull.s", (2, 1600, 1), 0.5, 2.0))
     assert maxerr(_ops().cos_kernel(x.to(DEV), y.to(DEV)), O.cos_kernel(x, y)) < 2e-6
     kyy = _ops().cos_kernel(y.to(DEV), y.to(DEV), diag_add=0.1)
-    assert maxerr(kyy, O.cos_kernel(y, y) + 0.1 * torch.eye(1600)[None]) < 2e-6
+    # on the diagonal c ~ 1 and exp((c-1)/T) amplifies the fp32 rounding of c by 1/T = 5
+    assert maxerr(kyy, O.cos_kernel(y, y) + 0.1 * torch.eye(1600)[None]) < 6e-6
 
 
 # ---- match_finalize / kde ----------------------------------------------------------------------
