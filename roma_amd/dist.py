@@ -1,0 +1,64 @@
+"""Multi-GPU sharding of image-pair batches: one process per GPU, contiguous blocks of pairs per rank, no data-path
+collective except ONE order-preserving gather of the results at the end.  `backend="nccl"` is RCCL
+over xGMI on ROCm; the same code runs on gloo for the CPU tests."""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(num_pairs: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Contiguous block [lo, hi) of pair indices for `rank`; the first (num_pairs % world_size) ranks get one extra."""
+    if not (0 <= rank < world_size):
+        raise ValueError(f"rank {rank} outside world of {world_size}")
+    q, r = divmod(num_pairs, world_size)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def gather_results(warp: torch.Tensor, certainty: torch.Tensor, num_pairs: int, dst: int = 0, group=None):
+    """Gather each rank's stacked results (p_rank, H, W2, 4) / (p_rank, H, W2) to `dst`, in pair order.
+    Uneven shards are padded to the largest shard for the collective and trimmed afterwards.  Returns
+    (warp, certainty) on dst, (None, None) elsewhere.  One direct gather: every peer sends its shard over its own
+    xGMI link (no ring)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if world == 1:
+        return warp, certainty
+    counts = [shard_range(num_pairs, world, r) for r in range(world)]
+    pmax = max(hi - lo for lo, hi in counts)
+    H, W2 = warp.shape[1], warp.shape[2]
+
+    def pad(t, tail):
+        if t.shape[0] == pmax:
+            return t.contiguous()
+        out = t.new_zeros((pmax,) + tail)
+        out[: t.shape[0]] = t
+        return out
+
+    w, c = pad(warp, (H, W2, 4)), pad(certainty, (H, W2))
+    if rank == dst:
+        wl = [torch.empty_like(w) for _ in range(world)]
+        cl = [torch.empty_like(c) for _ in range(world)]
+    else:
+        wl = cl = None
+    dist.gather(w, wl, dst=dst, group=group)
+    dist.gather(c, cl, dst=dst, group=group)
+    if rank != dst:
+        return None, None
+    ws = [wl[r][: hi - lo] for r, (lo, hi) in enumerate(counts)]
+    cs = [cl[r][: hi - lo] for r, (lo, hi) in enumerate(counts)]
+    return torch.cat(ws, dim=0), torch.cat(cs, dim=0)
+
+
+def match_sharded(match_fn: Callable, pairs: Sequence, dst: int = 0, group=None):
+    """Run `match_fn(list_of_local_pairs) -> (warp, certainty)` on this rank's contiguous shard of `pairs` and gather."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    lo, hi = shard_range(len(pairs), world, rank)
+    warp, cert = match_fn(list(pairs[lo:hi]))
+    if world == 1:
+        return warp, cert
+    return gather_results(warp, cert, len(pairs), dst=dst, group=group)

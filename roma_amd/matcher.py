@@ -256,7 +256,10 @@ class Decoder(nn.Module):
                 ys = y.permute(0, 2, 3, 1).reshape(b, hs * ws, -1)
                 mu = self.gps[s].posterior_rows(xs.float().contiguous(), ys.float().contiguous(), hs, ws)   # :377
                 tokens = torch.cat((mu.to(dtype), xs), dim=2)                                 # transformer/__init__.py:35-41
-                rows = self.embedding_decoder.forward_rows(tokens)                            # (b, hw, 4097)
+                # fp32 parameters, amp-dtype GEMMs/attention with fp32 LayerNorm/softmax: the reference's autocast
+                # region (transformer/__init__.py:31-32), here only around the library transformer
+                with torch.autocast("cuda", enabled=dtype != torch.float32, dtype=dtype if dtype != torch.float32 else None):
+                    rows = self.embedding_decoder.forward_rows(tokens)                        # (b, hw, 4097)
                 flow, certainty = ops.cls_rows_to_flow(rows, b, hs, ws)                       # :378-385
             delta, dcert = self.conv_refiner[s](x, y, flow, scale_factor=scale_factor, logits=certainty, dtype=dtype)   # :393
             flow = flow + ins * torch.stack((delta[:, 0] / (self.refine_init * w), delta[:, 1] / (self.refine_init * h)), dim=1)

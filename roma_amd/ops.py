@@ -18,6 +18,50 @@ from ._lib import ROMA_BF16, ROMA_F16, ROMA_F32, ROMA_NCHW, ROMA_NHWC, check
 _DT = {torch.float32: ROMA_F32, torch.float16: ROMA_F16, torch.bfloat16: ROMA_BF16}
 
 
+class KernelTimer:
+    """Optional HIP-event timing of individual kernel launches ON THE LAUNCH STREAM (torch's current stream).
+    bench.py enables it over the timed region to report the roofline of the dominant kernel; off by default."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []          # (name, algorithmic_bytes, start_event, end_event, tag)
+
+    def start(self):
+        self.records.clear()
+        self.enabled = True
+
+    def stop(self):
+        self.enabled = False
+
+    def wrap(self, name, nbytes, tag, launch):
+        if not self.enabled:
+            return launch()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        out = launch()
+        e.record()
+        self.records.append((name, nbytes, s, e, tag))
+        return out
+
+    def summary(self):
+        """{name: {"launches", "bytes", "seconds", "by_tag": {tag: [launches, bytes, seconds]}}} (call after a sync)."""
+        out = {}
+        for name, nbytes, s, e, tag in self.records:
+            d = out.setdefault(name, {"launches": 0, "bytes": 0, "seconds": 0.0, "by_tag": {}})
+            t = s.elapsed_time(e) * 1e-3
+            d["launches"] += 1
+            d["bytes"] += nbytes
+            d["seconds"] += t
+            bt = d["by_tag"].setdefault(tag, [0, 0, 0.0])
+            bt[0] += 1
+            bt[1] += nbytes
+            bt[2] += t
+        return out
+
+
+TIMER = KernelTimer()
+
+
 def _need_gpu(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -86,8 +130,12 @@ def local_correlation(feature0, feature1, local_radius, padding_mode="zeros", fl
     lo, po, o = feat_layout(out)
     if o is not out or tuple(out.shape) != (B, K, H, W) or out.dtype != feature0.dtype:
         raise ValueError("out must be a (B,K,h,w) tensor of the input dtype, contiguous or channels-last")
-    check(_lib.load().roma_local_corr(_p(f0), _p(f1), _p(flow), _p(out), B, C, H, W, r, _dt(f0), l0, p0, p1, lo, po, _stream()),
-          "roma_local_corr")
+    es = f0.element_size()
+    # algorithmic bytes of SURVEY §8(d): f0 + f1 + flow(fp32) + out
+    nbytes = 2 * B * C * H * W * es + B * 2 * H * W * 4 + B * K * H * W * es
+    TIMER.wrap("local_corr", nbytes, f"C{C}_h{H}x{W}_r{r}",
+               lambda: check(_lib.load().roma_local_corr(_p(f0), _p(f1), _p(flow), _p(out), B, C, H, W, r, _dt(f0), l0, p0, p1,
+                                                         lo, po, _stream()), "roma_local_corr"))
     return out
 
 

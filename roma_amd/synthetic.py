@@ -1,0 +1,62 @@
+"""Deterministic synthetic weights and image pairs for bench.py / smoke() (no datasets or checkpoints offline).
+Variance-preserving random parameters (N(0, 1/fan_in) weights, non-trivial BatchNorm statistics), generated on the
+CPU with a seeded torch.Generator so that every rank and the CPU oracle hold bit-identical values."""
+from __future__ import annotations
+
+import math
+
+import torch
+
+
+def synthetic_state_dict(shapes: dict, seed: int = 0, gains: dict | None = None) -> dict:
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for k in sorted(shapes):
+        shape = tuple(shapes[k])
+        last = k.rsplit(".", 1)[-1]
+        gain = 1.0
+        for pat, v in (gains or {}).items():
+            if pat in k:
+                gain = v
+        if last == "num_batches_tracked":
+            t = torch.zeros(shape, dtype=torch.int64)
+        elif last == "running_var":
+            t = torch.rand(shape, generator=g) + 0.5
+        elif last == "running_mean":
+            t = torch.randn(shape, generator=g) * 0.1
+        elif last == "gamma":
+            t = torch.rand(shape, generator=g) + 0.5
+        elif last in ("cls_token", "pos_embed", "mask_token"):
+            t = torch.randn(shape, generator=g) * 0.02
+        elif last == "bias":
+            t = torch.randn(shape, generator=g) * 0.05 * gain
+        elif len(shape) == 1:
+            t = torch.rand(shape, generator=g) + 0.5
+        else:
+            fan_in = 1
+            for s in shape[1:]:
+                fan_in *= s
+            t = torch.randn(shape, generator=g) * (gain / math.sqrt(fan_in))
+        out[k] = t
+    return out
+
+
+SYNTH_GAINS = {"to_out": 6.0, "pos_conv": 4.0}
+
+
+def load_synthetic_weights(model, seed: int = 0):
+    """Fill a roma model (product or oracle: same key layout) and its DINOv2 trunk in place."""
+    vit = model.encoder.dinov2_vitl14[0]
+    sd = synthetic_state_dict({k: v.shape for k, v in model.state_dict().items()}, seed, SYNTH_GAINS)
+    model.load_state_dict(sd)
+    vd = synthetic_state_dict({"dinov2." + k: v.shape for k, v in vit.state_dict().items()}, seed)
+    vit.load_state_dict({k[len("dinov2."):]: v for k, v in vd.items()})
+    return model
+
+
+def synthetic_pair(index: int, lo=(560, 560), hi=(864, 864)):
+    """One image pair ~ N(0,1) (ImageNet-normalised statistics): (A_lo, B_lo, A_hi, B_hi), each (1,3,h,w) fp32,
+    generator seed 1234 + pair index."""
+    g = torch.Generator().manual_seed(1234 + index)
+    mk = lambda s: torch.randn(1, 3, s[0], s[1], generator=g)   # noqa: E731
+    return mk(lo), mk(lo), mk(hi), mk(hi)
