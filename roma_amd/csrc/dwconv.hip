@@ -34,29 +34,63 @@ __global__ __launch_bounds__(256) void dwconv5x5_kernel(const T* __restrict__ x,
 #pragma unroll
       for (int e = 0; e < E; ++e) acc[o][e] = 0.f;
     const T* xb = x + (size_t)b * H * W * x_pitch + c0;
+    // interior strips (all but a 2-pixel frame) run with unconditional loads; a guarded load makes hipcc branch and
+    // wait vmcnt(0) per element.  Border strips clamp the address and zero the tap through its weight.
+    const bool interior = yo >= 2 && yo + 2 < H && xs >= 2 && xs + XS + 2 <= W;
+    if (interior) {
 #pragma unroll
-    for (int dy = 0; dy < 5; ++dy) {
-      const int yi = yo + dy - 2;
-      if (yi < 0 || yi >= H) continue;
-      float wr[5][E];
+      for (int dy = 0; dy < 5; ++dy) {
+        float wr[5][E];
 #pragma unroll
-      for (int dx = 0; dx < 5; ++dx)
+        for (int dx = 0; dx < 5; ++dx)
 #pragma unroll
-        for (int e = 0; e < E; e += 4)
-          *reinterpret_cast<float4_t*>(&wr[dx][e]) = *reinterpret_cast<const float4_t*>(w + (size_t)(dy * 5 + dx) * C + c0 + e);
-      const T* row = xb + (size_t)yi * W * x_pitch;
+          for (int e = 0; e < E; e += 4)
+            *reinterpret_cast<float4_t*>(&wr[dx][e]) = *reinterpret_cast<const float4_t*>(w + (size_t)(dy * 5 + dx) * C + c0 + e);
+        const T* row = xb + ((size_t)(yo + dy - 2) * W + (xs - 2)) * x_pitch;
+        u32x4 raw[XS + 4];
 #pragma unroll
-      for (int cx = 0; cx < XS + 4; ++cx) {
-        const int xi = xs + cx - 2;
-        if (xi < 0 || xi >= W) continue;
-        float f[E];
-        unpack16<T>(*reinterpret_cast<const u32x4*>(row + (size_t)xi * x_pitch), f);
+        for (int cx = 0; cx < XS + 4; ++cx) raw[cx] = *reinterpret_cast<const u32x4*>(row + (size_t)cx * x_pitch);
 #pragma unroll
-        for (int dx = 0; dx < 5; ++dx) {
-          const int o = cx - dx;
-          if (o >= 0 && o < XS) {
+        for (int cx = 0; cx < XS + 4; ++cx) {
+          float f[E];
+          unpack16<T>(raw[cx], f);
 #pragma unroll
-            for (int e = 0; e < E; ++e) acc[o][e] = __builtin_fmaf(wr[dx][e], f[e], acc[o][e]);
+          for (int dx = 0; dx < 5; ++dx) {
+            const int o = cx - dx;
+            if (o >= 0 && o < XS) {
+#pragma unroll
+              for (int e = 0; e < E; ++e) acc[o][e] = __builtin_fmaf(wr[dx][e], f[e], acc[o][e]);
+            }
+          }
+        }
+      }
+    } else {
+#pragma unroll 1
+      for (int dy = 0; dy < 5; ++dy) {
+        const int yi = yo + dy - 2;
+        const float my = (yi >= 0 && yi < H) ? 1.f : 0.f;
+        const int yc = min(max(yi, 0), H - 1);
+        float wr[5][E];
+#pragma unroll
+        for (int dx = 0; dx < 5; ++dx)
+#pragma unroll
+          for (int e = 0; e < E; e += 4)
+            *reinterpret_cast<float4_t*>(&wr[dx][e]) = *reinterpret_cast<const float4_t*>(w + (size_t)(dy * 5 + dx) * C + c0 + e);
+        const T* row = xb + (size_t)yc * W * x_pitch;
+#pragma unroll
+        for (int cx = 0; cx < XS + 4; ++cx) {
+          const int xi = xs + cx - 2;
+          const float m = (xi >= 0 && xi < W) ? my : 0.f;
+          const int xc = min(max(xi, 0), W - 1);
+          float f[E];
+          unpack16<T>(*reinterpret_cast<const u32x4*>(row + (size_t)xc * x_pitch), f);
+#pragma unroll
+          for (int dx = 0; dx < 5; ++dx) {
+            const int o = cx - dx;
+            if (o >= 0 && o < XS) {
+#pragma unroll
+              for (int e = 0; e < E; ++e) acc[o][e] = __builtin_fmaf(wr[dx][e] * m, f[e], acc[o][e]);
+            }
           }
         }
       }

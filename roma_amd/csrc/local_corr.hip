@@ -251,6 +251,280 @@ __global__ __launch_bounds__(kThreads) void local_corr_kernel(LCParams p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Channels-last fast path.
+//  * The tile's box of f1 rows is staged 64 bytes of channels at a time by LDS-DMA (global_load_lds_dwordx4: no VGPR
+//    round trip, no ds_write), with a per-thread source-address plan computed once; every DMA is unconditional.
+//  * LDS rows are 64 bytes, unpadded (an LDS-DMA wave-instruction writes 1 KiB linearly), with the packet index
+//    XOR-swizzled by (row >> 2) & 3: any 16 rows with distinct (row mod 16) then occupy 16 distinct 16-byte slots.
+//  * LDS reads are bank-conflict free BY CONSTRUCTION, for any flow: ds_read_b128 serves a wavefront in four fixed
+//    16-lane groups; each group works on ONE pixel at a time, its 16 lanes take 16 consecutive window positions
+//    q = 16 t + idx (runs of 2r+2 consecutive target columns over consecutive target rows), and the staged box uses a
+//    row pitch congruent to (2r+2) mod 16, so the runs tile the 16 residues.  The pixel's f0 row is a broadcast read.
+//    (A thread-per-pixel mapping measured 56 % of all LDS cycles as bank conflicts, profiles/r01_local_corr_pmc.md.)
+//  * 32-pixel tiles (16 for r >= 6) and <= 30 KiB of LDS per workgroup: 5 workgroups per CU hide the DMA latency of
+//    one another (single LDS buffer, two barriers per chunk).
+// ------------------------------------------------------------------------------------------------------------------
+template <int R> struct LCFast {
+  static constexpr int TP = R <= 5 ? 32 : 16;                       // pixels per tile
+  static constexpr int TW = R <= 5 ? 8 : 4, TH = TP / TW;
+  static constexpr int MAXR = R <= 3 ? 384 : (R <= 5 ? 512 : 640);  // LDS capacity in staged rows (multiple of 16)
+};
+
+__device__ __forceinline__ int swz(int row, int k) { return row * 4 + (k ^ ((row >> 2) & 3)); }
+
+// one LDS-DMA wave-instruction: lane i of the wavefront copies 16 bytes from its own global address to
+// lds_wave_base + 16*i (the LDS side is wave-uniform base + lane*16 by hardware definition)
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned char* lds_wave_base) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+#endif
+}
+
+template <typename T, int R>
+__global__ __launch_bounds__(kThreads) void local_corr_nhwc_kernel(LCParams p) {
+  using G = LCFast<R>;
+  constexpr int TW = G::TW, TH = G::TH, TP = G::TP;
+  constexpr int N1 = 2 * R + 1, N2 = 2 * R + 2, Q = N2 * N2, K = N1 * N1;
+  constexpr int NPIX = TP / 16;                 // pixels handled (one after the other) by each 16-lane group
+  constexpr int NIT = (Q + 15) / 16;            // window positions per lane and pixel
+  constexpr int E16 = ElemTraits<T>::kPer16B;
+  constexpr int PK = 4, CC = PK * E16;
+  constexpr int MAXR = G::MAXR;
+  constexpr int NROWS = TP + MAXR;              // f0 rows + staged box
+  constexpr int NL = (NROWS * PK + kThreads - 1) / kThreads;   // DMA rounds (64 rows each)
+  constexpr int ZROW = NL * (kThreads / PK);    // 16 all-zero rows right after the DMA'd buffer (never a DMA target)
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u32x4* s_rows = reinterpret_cast<u32x4*>(smem);             // row r, packet k at s_rows[swz(r, k)]
+  int* s_meta = reinterpret_cast<int*>(s_rows + NL * kThreads + 16 * PK);
+  int* s_x0 = s_meta + 8;
+  int* s_y0 = s_x0 + TP;
+  float* s_ax = reinterpret_cast<float*>(s_y0 + TP);
+  float* s_ay = s_ax + TP;
+  float* s_D = reinterpret_cast<float*>(s_rows);              // aliased after the channel loop: [TP][Q+1]
+
+  const int tid = threadIdx.x;
+  const int ntile = p.tiles_x * p.tiles_y;
+  const int wid = xcd_remap(blockIdx.x, gridDim.x);
+  const int b = wid / ntile;
+  const int t = wid - b * ntile;
+  const int ty0 = (t / p.tiles_x) * TH, tx0 = (t % p.tiles_x) * TW;
+  const int H = p.H, W = p.W;
+
+  if (tid < 4) s_meta[tid] = (tid < 2) ? 0x7fffffff : -0x7fffffff;
+  __syncthreads();
+  if (tid < TP) {
+    const int y = ty0 + tid / TW, x = tx0 + tid % TW;
+    int x0 = 0, y0 = 0;
+    float ax = 0.f, ay = 0.f;
+    if (y < H && x < W) {
+      float fx, fy;
+      if (p.flow) {
+        fx = p.flow[((size_t)(b * 2 + 0) * H + y) * W + x];
+        fy = p.flow[((size_t)(b * 2 + 1) * H + y) * W + x];
+      } else {
+        fx = -1.f + (2.f * x + 1.f) / W;
+        fy = -1.f + (2.f * y + 1.f) / H;
+      }
+      float px = ((fx + 1.f) * W - 1.f) * 0.5f, py = ((fy + 1.f) * H - 1.f) * 0.5f;
+      if (!(px > -1e6f && px < 1e6f)) px = -1e6f;
+      if (!(py > -1e6f && py < 1e6f)) py = -1e6f;
+      const float fx0 = floorf(px), fy0 = floorf(py);
+      ax = px - fx0;
+      ay = py - fy0;
+      x0 = (int)fx0;
+      y0 = (int)fy0;
+      const int lox = max(x0 - R, 0), hix = min(x0 + R + 1, W - 1);
+      const int loy = max(y0 - R, 0), hiy = min(y0 + R + 1, H - 1);
+      if (lox <= hix && loy <= hiy) {
+        atomicMin(&s_meta[0], lox);
+        atomicMin(&s_meta[1], loy);
+        atomicMax(&s_meta[2], hix);
+        atomicMax(&s_meta[3], hiy);
+      }
+    }
+    s_x0[tid] = x0;
+    s_y0[tid] = y0;
+    s_ax[tid] = ax;
+    s_ay[tid] = ay;
+  }
+  __syncthreads();
+  const int bx0 = s_meta[0], by0 = s_meta[1];
+  const bool empty = s_meta[2] < bx0 || s_meta[3] < by0;
+  const int bw = empty ? 0 : s_meta[2] - bx0 + 1, bh = empty ? 0 : s_meta[3] - by0 + 1;
+  // LDS row pitch of the box: smallest value >= bw congruent to (2r+2) mod 16 (a full 16-wide window needs none)
+  const int bwp = (empty || N2 == 16) ? bw : bw + ((N2 - bw) & 15);
+  const int nrows = bwp * bh;
+  const bool staged = nrows <= MAXR;
+  constexpr int zero_row = ZROW;
+
+  // 16-lane ds_read_b128 service groups of a wavefront: {0-3,12-15,20-27}, {4-11,16-19,28-31}, and the same +32
+  int g16, idx;
+  {
+    const int lane = tid & 63, l5 = lane & 31;
+    int hg;
+    if (l5 < 4) { hg = 0; idx = l5; }
+    else if (l5 < 12) { hg = 1; idx = l5 - 4; }
+    else if (l5 < 16) { hg = 0; idx = l5 - 8; }
+    else if (l5 < 20) { hg = 1; idx = l5 - 8; }
+    else if (l5 < 28) { hg = 0; idx = l5 - 12; }
+    else { hg = 1; idx = l5 - 16; }
+    g16 = (tid >> 6) * 4 + (lane >> 5) * 2 + hg;
+  }
+  const T* f0 = static_cast<const T*>(p.f0) + (size_t)b * H * W * p.f0_pitch;
+  const T* f1 = static_cast<const T*>(p.f1) + (size_t)b * H * W * p.f1_pitch;
+  float acc[NPIX][NIT];
+#pragma unroll
+  for (int a = 0; a < NPIX; ++a)
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) acc[a][i] = 0.f;
+
+  if (staged) {
+    // LDS offsets (in packets, before the per-k swizzle) of this lane's window rows
+    int rowidx[NPIX][NIT];
+#pragma unroll
+    for (int a = 0; a < NPIX; ++a) {
+      const int pix = a * 16 + g16;
+      const bool pvalid = (ty0 + pix / TW < H) && (tx0 + pix % TW < W);
+      const int px0 = s_x0[pix], py0 = s_y0[pix];
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) {
+        const int q = i * 16 + idx;
+        const int yy = py0 - R + q / N2, xx = px0 - R + q % N2;
+        const bool ok = pvalid && (q < Q) && (yy >= 0) && (yy < H) && (xx >= 0) && (xx < W);
+        rowidx[a][i] = ok ? TP + (yy - by0) * bwp + (xx - bx0) : zero_row;
+      }
+    }
+    for (int i = tid; i < 16 * PK; i += kThreads) s_rows[ZROW * PK + i] = u32x4{0, 0, 0, 0};
+    // ---- DMA plan: LDS packet slot s = l*256 + tid holds (row = s/4, k = (s%4) ^ ((row>>2)&3)); its global source is
+    // fixed for the whole channel loop.  Slots that hold nothing (pitch padding, rows beyond the box) read a valid dummy
+    // address and are never consumed. ----
+    const T* src[NL];
+    const int used_rows = TP + nrows;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      const int slot = l * kThreads + tid;
+      const int row = slot >> 2;
+      const int k = (slot & 3) ^ ((row >> 2) & 3);
+      int y = ty0, x = tx0, pitch = p.f0_pitch;
+      const T* base = f0;
+      if (row < TP) {
+        y = min(ty0 + row / TW, H - 1);
+        x = min(tx0 + row % TW, W - 1);
+      } else if (row < used_rows) {
+        const int rr = row - TP;
+        const int ry = rr / bwp, rx = rr - ry * bwp;
+        if (rx < bw) {
+          y = by0 + ry;
+          x = bx0 + rx;
+          base = f1;
+          pitch = p.f1_pitch;
+        }
+      }
+      src[l] = base + ((size_t)y * W + x) * pitch + k * E16;
+    }
+    const int nl_used = (((used_rows + 15) & ~15) * PK + kThreads - 1) / kThreads;   // DMA rounds that carry data
+
+    for (int c0 = 0; c0 < p.C; c0 += CC) {
+#pragma unroll
+      for (int l = 0; l < NL; ++l)
+        if (l < nl_used)
+          dma16(src[l] + c0, smem + (size_t)(l * kThreads + (tid & ~63)) * 16);
+      __syncthreads();                                          // vmcnt(0) + barrier: the chunk has landed
+#pragma unroll
+      for (int a = 0; a < NPIX; ++a) {
+        const int prow = a * 16 + g16;
+        u32x4 fa[PK];
+#pragma unroll
+        for (int k = 0; k < PK; ++k) fa[k] = s_rows[swz(prow, k)];                      // broadcast within the group
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+          const int r0 = rowidx[a][i];
+          const int sw = (r0 >> 2) & 3;
+          float sacc = acc[a][i];
+#pragma unroll
+          for (int k = 0; k < PK; ++k) sacc = dot16<T>(fa[k], s_rows[r0 * 4 + (k ^ sw)], sacc);
+          acc[a][i] = sacc;
+        }
+      }
+      __syncthreads();                                          // everyone is done reading before the next DMA lands
+    }
+  } else {
+    // incoherent tile: every (pixel, position) row straight from L2/HBM; correct for any flow, not the fast path
+#pragma unroll
+    for (int a = 0; a < NPIX; ++a) {
+      const int pix = a * 16 + g16;
+      const int y = ty0 + pix / TW, x = tx0 + pix % TW;
+      const bool pvalid = (y < H) && (x < W);
+      const int px0 = s_x0[pix], py0 = s_y0[pix];
+#pragma unroll 1
+      for (int c0 = 0; c0 < p.C; c0 += CC) {
+        u32x4 fa[PK];
+#pragma unroll
+        for (int k = 0; k < PK; ++k)
+          fa[k] = *reinterpret_cast<const u32x4*>(f0 + ((size_t)min(y, H - 1) * W + min(x, W - 1)) * p.f0_pitch + c0 + k * E16);
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+          const int q = i * 16 + idx;
+          const int yy = py0 - R + q / N2, xx = px0 - R + q % N2;
+          const bool ok = pvalid && (q < Q) && (yy >= 0) && (yy < H) && (xx >= 0) && (xx < W);
+          const T* rsrc = f1 + ((size_t)min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1)) * p.f1_pitch + c0;
+          float sacc = 0.f;
+#pragma unroll
+          for (int k = 0; k < PK; ++k) sacc = dot16<T>(fa[k], *reinterpret_cast<const u32x4*>(rsrc + k * E16), sacc);
+          acc[a][i] += ok ? sacc : 0.f;
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int a = 0; a < NPIX; ++a)
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int q = i * 16 + idx;
+      if (q < Q) s_D[(a * 16 + g16) * (Q + 1) + q] = acc[a][i] * p.scale;
+    }
+  __syncthreads();
+  T* out = static_cast<T*>(p.out);
+  for (int e = tid; e < TP * K; e += kThreads) {
+    int pix, k;
+    if (p.out_nhwc) { pix = e / K; k = e - pix * K; } else { k = e / TP; pix = e - k * TP; }
+    const int y = ty0 + pix / TW, x = tx0 + pix % TW;
+    if (y >= H || x >= W) continue;
+    const int iy = k / N1, ix = k - iy * N1;
+    const float ax = s_ax[pix], ay = s_ay[pix];
+    const float* d = s_D + pix * (Q + 1) + iy * N2 + ix;
+    const float top = d[0] + ax * (d[1] - d[0]);
+    const float bot = d[N2] + ax * (d[N2 + 1] - d[N2]);
+    out[feat_off(p.out_nhwc, b, k, y, x, p.out_pitch, H, W)] = from_f32<T>(top + ay * (bot - top));
+  }
+}
+
+template <typename T, int R>
+int launch_lc_nhwc(LCParams p, hipStream_t stream) {
+  using G = LCFast<R>;
+  constexpr int TP = G::TP, Q = (2 * R + 2) * (2 * R + 2);
+  constexpr int NROWS = TP + G::MAXR;
+  constexpr int NL = (NROWS * 4 + kThreads - 1) / kThreads;
+  p.tiles_x = (p.W + G::TW - 1) / G::TW;
+  p.tiles_y = (p.H + G::TH - 1) / G::TH;
+  p.max_rows = G::MAXR;
+  size_t body = (size_t)NL * kThreads * 16 + 16 * 4 * 16;      // DMA'd rows + 16 zero rows
+  const size_t need_D = (size_t)TP * (Q + 1) * 4;
+  if (body < need_D) body = need_D;
+  const size_t meta = (8 + 2 * TP) * 4 + 2 * TP * 4;
+  static_assert((size_t)NL * kThreads * 16 >= (size_t)TP * (Q + 1) * 4, "D exchange must fit in the row buffer");
+  const size_t smem = body + meta;
+  const int grid = p.B * p.tiles_x * p.tiles_y;
+  hipLaunchKernelGGL((local_corr_nhwc_kernel<T, R>), dim3(grid), dim3(kThreads), smem, stream, p);
+  ROMA_CHECK_LAUNCH();
+}
+
 template <typename T, int R>
 int launch_lc(LCParams p, hipStream_t stream) {
   using G = LCGeom<R>;
@@ -272,16 +546,22 @@ int launch_lc(LCParams p, hipStream_t stream) {
   ROMA_CHECK_LAUNCH();
 }
 
+template <typename T, int R>
+int launch_any(const LCParams& p, hipStream_t s) {
+  constexpr int CC = 4 * ElemTraits<T>::kPer16B;                // the fast path streams whole 64-byte channel chunks
+  return (p.in_nhwc && p.C % CC == 0) ? launch_lc_nhwc<T, R>(p, s) : launch_lc<T, R>(p, s);
+}
+
 template <typename T>
 int dispatch_r(const LCParams& p, int r, hipStream_t s) {
   switch (r) {
-    case 1: return launch_lc<T, 1>(p, s);
-    case 2: return launch_lc<T, 2>(p, s);
-    case 3: return launch_lc<T, 3>(p, s);
-    case 4: return launch_lc<T, 4>(p, s);
-    case 5: return launch_lc<T, 5>(p, s);
-    case 6: return launch_lc<T, 6>(p, s);
-    case 7: return launch_lc<T, 7>(p, s);
+    case 1: return launch_any<T, 1>(p, s);
+    case 2: return launch_any<T, 2>(p, s);
+    case 3: return launch_any<T, 3>(p, s);
+    case 4: return launch_any<T, 4>(p, s);
+    case 5: return launch_any<T, 5>(p, s);
+    case 6: return launch_any<T, 6>(p, s);
+    case 7: return launch_any<T, 7>(p, s);
   }
   set_error("roma_local_corr: radius %d outside 1..7", r);
   return ROMA_E_UNSUPPORTED;

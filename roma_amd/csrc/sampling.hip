@@ -53,22 +53,24 @@ __global__ __launch_bounds__(256) void warp_nhwc_kernel(const T* __restrict__ sr
     const float fx = flow[((size_t)(b * 2 + 0) * H + y) * W + x];
     const float fy = flow[((size_t)(b * 2 + 1) * H + y) * W + x];
     const Corner c = corners(fx, fy, Hs, Ws);
-    float acc[E16];
-#pragma unroll
-    for (int e = 0; e < E16; ++e) acc[e] = 0.f;
+    // all four taps are loaded unconditionally from clamped coordinates and masked through their weights: a guarded
+    // load would make hipcc branch and wait vmcnt(0) per tap (four serial L2 round trips)
     const T* base = src + (size_t)b * Hs * Ws * src_pitch + (size_t)k * E16;
-    auto tap = [&](bool ok, int yy, int xx, float w) {
-      if (ok) {
-        float f[E16];
-        unpack16<T>(*reinterpret_cast<const u32x4*>(base + ((size_t)yy * Ws + xx) * src_pitch), f);
+    const int xa = min(max(c.x0, 0), Ws - 1), xb = min(max(c.x0 + 1, 0), Ws - 1);
+    const int ya = min(max(c.y0, 0), Hs - 1), yb = min(max(c.y0 + 1, 0), Hs - 1);
+    const u32x4 v00 = *reinterpret_cast<const u32x4*>(base + ((size_t)ya * Ws + xa) * src_pitch);
+    const u32x4 v01 = *reinterpret_cast<const u32x4*>(base + ((size_t)ya * Ws + xb) * src_pitch);
+    const u32x4 v10 = *reinterpret_cast<const u32x4*>(base + ((size_t)yb * Ws + xa) * src_pitch);
+    const u32x4 v11 = *reinterpret_cast<const u32x4*>(base + ((size_t)yb * Ws + xb) * src_pitch);
+    const float w00 = c.v00 ? c.w00 : 0.f, w01 = c.v01 ? c.w01 : 0.f, w10 = c.v10 ? c.w10 : 0.f, w11 = c.v11 ? c.w11 : 0.f;
+    float f00[E16], f01[E16], f10[E16], f11[E16], acc[E16];
+    unpack16<T>(v00, f00);
+    unpack16<T>(v01, f01);
+    unpack16<T>(v10, f10);
+    unpack16<T>(v11, f11);
 #pragma unroll
-        for (int e = 0; e < E16; ++e) acc[e] = __builtin_fmaf(w, f[e], acc[e]);
-      }
-    };
-    tap(c.v00, c.y0, c.x0, c.w00);
-    tap(c.v01, c.y0, c.x0 + 1, c.w01);
-    tap(c.v10, c.y0 + 1, c.x0, c.w10);
-    tap(c.v11, c.y0 + 1, c.x0 + 1, c.w11);
+    for (int e = 0; e < E16; ++e)
+      acc[e] = __builtin_fmaf(w11, f11[e], __builtin_fmaf(w10, f10[e], __builtin_fmaf(w01, f01[e], w00 * f00[e])));
     *reinterpret_cast<u32x4*>(dst + pix * dst_pitch + (size_t)k * E16) = pack16<T>(acc);
   }
 }

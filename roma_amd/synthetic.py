@@ -54,9 +54,33 @@ def load_synthetic_weights(model, seed: int = 0):
     return model
 
 
-def synthetic_pair(index: int, lo=(560, 560), hi=(864, 864)):
-    """One image pair ~ N(0,1) (ImageNet-normalised statistics): (A_lo, B_lo, A_hi, B_hi), each (1,3,h,w) fp32,
-    generator seed 1234 + pair index."""
+def _texture(g, size, octaves=6):
+    """Smooth multi-scale random texture (3,size,size): a sum of bilinearly up-sampled noise octaves, unit variance."""
+    import torch.nn.functional as F
+    img = torch.zeros(1, 3, size, size)
+    for o in range(octaves):
+        n = max(4, size >> (octaves - 1 - o))
+        img = img + F.interpolate(torch.randn(1, 3, n, n, generator=g), size=(size, size), mode="bilinear", align_corners=False) * (0.6 ** o)
+    img = img - img.mean(dim=(2, 3), keepdim=True)
+    return img / img.std(dim=(2, 3), keepdim=True)
+
+
+def synthetic_pair(index: int, lo=(560, 560), hi=(864, 864), rot_deg=8.0, scale=1.08, shift=0.04):
+    """One synthetic image pair with a KNOWN relation, generator seed 1234 + pair index: A is a smooth random texture
+    with ImageNet-normalised statistics (zero mean, unit variance per channel), B is A seen through a similarity warp
+    (rotation, scale, shift) plus 2 % sensor noise — so the matcher has real correspondences to find and the predicted
+    flow is spatially coherent, as for photographs.  Returns (A_lo, B_lo, A_hi, B_hi), each (1,3,h,w) fp32."""
+    import torch.nn.functional as F
     g = torch.Generator().manual_seed(1234 + index)
-    mk = lambda s: torch.randn(1, 3, s[0], s[1], generator=g)   # noqa: E731
-    return mk(lo), mk(lo), mk(hi), mk(hi)
+    base = max(hi[0], hi[1], lo[0], lo[1])
+    A = _texture(g, base)
+    c, s_ = math.cos(math.radians(rot_deg)) * scale, math.sin(math.radians(rot_deg)) * scale
+    theta = torch.tensor([[[c, -s_, shift], [s_, c, -shift]]], dtype=torch.float32)
+    B = F.grid_sample(A, F.affine_grid(theta, (1, 3, base, base), align_corners=False), mode="bilinear",
+                      padding_mode="reflection", align_corners=False)
+    B = B + 0.02 * torch.randn(B.shape, generator=g)
+
+    def rs(img, size):
+        return img if tuple(img.shape[-2:]) == tuple(size) else F.interpolate(img, size=size, mode="bilinear", align_corners=False, antialias=True)
+
+    return rs(A, lo), rs(B, lo), rs(A, hi), rs(B, hi)

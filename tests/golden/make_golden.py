@@ -371,6 +371,14 @@ def gen_e2e(ref, full=False):
         out["c560_warp_sample"] = warp.numpy()[::8, ::8].copy()
         out["c560_cert_sample"] = cert.numpy()[::8, ::8].copy()
         save("e2e_560", **{k: v for k, v in out.items() if k.startswith("c560")})
+        # BASELINE.json configs[1] on the real pair: full 560 -> 864 coarse-to-fine (about a minute on 8 cores)
+        model.upsample_preds = True
+        model.upsample_res = (864, 864)
+        t = time.time()
+        warp, cert = model.match(pa, pb, device="cpu")
+        print(f"  560->864 full match: {time.time()-t:.1f}s")
+        save("e2e_864", warp_stats=R.checksum(warp.numpy()), cert_stats=R.checksum(cert.numpy()),
+             warp_sample=warp.numpy()[::6, ::6].copy(), cert_sample=cert.numpy()[::6, ::6].copy())
     save("e2e_112", **{k: v for k, v in out.items() if k.startswith("r112")})
 
 

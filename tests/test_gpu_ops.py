@@ -229,11 +229,15 @@ def test_kde_golden_and_full_size():
     x = H.T(cases.kde_inputs(), DEV)
     assert maxerr(_ops().kde(x, half=False), H.T(g["fp32"])) < 1e-3
     assert maxerr(_ops().kde(x, half=False, down=4), H.T(g["down4"])) < 1e-3
-    # half=True: reference does the whole cdist in fp16; ours rounds the inputs to fp16 and sums in fp32.
+    # half=True: the reference runs the whole cdist (x^2 + y^2 - 2xy) in fp16 arithmetic, which is itself ~10 % off its
+    # own fp32 value; the kernel rounds the INPUTS to fp16 like the reference and sums in fp32.  Parity is therefore
+    # tight against fp32-math-on-fp16-inputs and only loose (20 %) against the reference's fp16 fixture.
     d16 = _ops().kde(x, half=True)
     assert d16.dtype == torch.float16
+    tight = O.kde(x.cpu().half().float(), half=False)
+    assert float(((d16.float().cpu() - tight).abs() / tight.clamp_min(1)).max()) < 2e-3
     rel = ((d16.float().cpu() - H.T(g["fp16"])).abs() / H.T(g["fp16"]).abs().clamp_min(1)).max()
-    assert float(rel) < 2e-2
+    assert float(rel) < 0.2
     xf = H.T(R.uniform("kdefull", (10000, 4), -1, 1))
     ref = O.kde(xf, half=False)
     out = _ops().kde(xf.to(DEV), half=False)
