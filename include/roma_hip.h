@@ -83,6 +83,13 @@ int roma_cls_to_flow_refine(const void* logits, float* flow_out, float* cert_out
 int roma_cos_kernel(const float* x, const float* y, float* K, int B, int N, int M, int D,
                     float T, float eps, float diag_add, void* stream);
 
+/* One diagonal-block step of the blocked Cholesky solve that replaces GP.forward's inv(K_yy + sigma I) @ f —
+ * matcher.py:259-263.  For each of the B matrices: the nb x nb block at A (row-major, leading dimension lda, batch stride
+ * strideA; only its lower triangle is read) is replaced by its Cholesky factor L (lower), and W (nb x nb, ldw, strideW)
+ * receives L^-1.  info[b] != 0 reports a non-positive pivot (1-based).  nb <= 64.  The panel and substitution steps
+ * around it are plain GEMMs done by the caller (roma_amd/ops.py: spd_solve). */
+int roma_chol_diag_block(float* A, int lda, long strideA, float* W, int ldw, long strideW, int nb, int B, int* info, void* stream);
+
 /* match() post-processing — matcher.py:656-662, 684-718: certainty attenuation by the coarse scale-16 certainty,
  * sigmoid, zeroing where |flow|>1, clamp, symmetric concat.
  *   flow (2P,2,H,W), cert (2P,1,H,W) fp32 planar: first P = A->B, last P = B->A (forward_symmetric, matcher.py:516-528)

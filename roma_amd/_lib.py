@@ -25,6 +25,7 @@ SIGNATURES = {
     "roma_flow_update": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p],
     "roma_cls_to_flow_refine": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_long, c_long, c_int, c_void_p],
     "roma_cos_kernel": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_void_p],
+    "roma_chol_diag_block": [c_void_p, c_int, c_long, c_void_p, c_int, c_long, c_int, c_int, c_void_p, c_void_p],
     "roma_match_finalize": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "roma_kde_density": [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
     "roma_dwconv5x5_bn_relu": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],

@@ -145,8 +145,9 @@ class CosKernel(nn.Module):
 
 class GP(nn.Module):
     """Posterior mean of the Fourier positional basis (no_cov=True, the shipped configuration).  The two kernel
-    matrices come from the fp32-MFMA CosKernel kernel; `inv(K_yy + sigma I) @ f` (matcher.py:259-263) is solved by
-    Cholesky (K_yy + sigma I is SPD) instead of forming the inverse; the dead K_xx (matcher.py:255) is skipped."""
+    matrices come from the fp32-MFMA CosKernel kernel; `inv(K_yy + sigma I) @ f` (matcher.py:259-263) is a hand-blocked
+    Cholesky solve (ops.spd_solve: K_yy + sigma I is SPD; the vendor batched potrf/potrs takes ~10 ms at 1600 x 1600,
+    the reference's explicit inverse ~20 ms); the dead K_xx (matcher.py:255) is skipped."""
 
     def __init__(self, gp_dim=512, T=0.2, sigma_noise=0.1, kernel=None, **_):
         super().__init__()
@@ -174,16 +175,14 @@ class GP(nn.Module):
         ys = y.float().flatten(2).transpose(1, 2).contiguous()
         K_yy = ops.cos_kernel(ys, ys, T=self.K.T, diag_add=self.sigma_noise)
         K_xy = ops.cos_kernel(xs, ys, T=self.K.T)
-        L = torch.linalg.cholesky(K_yy)
-        mu = K_xy @ torch.cholesky_solve(self.basis(b, h2, w2, x.device), L)
+        mu = K_xy @ ops.spd_solve(K_yy, self.basis(b, h2, w2, x.device).contiguous())
         return mu.transpose(1, 2).reshape(b, self.dim, h1, w1)
 
     def posterior_rows(self, xs, ys, h2, w2):
         """Token-major variant used by the Decoder: xs, ys (B,N,D) fp32 -> mu (B,N,gp_dim) fp32."""
         K_yy = ops.cos_kernel(ys, ys, T=self.K.T, diag_add=self.sigma_noise)
         K_xy = ops.cos_kernel(xs, ys, T=self.K.T)
-        L = torch.linalg.cholesky(K_yy)
-        return K_xy @ torch.cholesky_solve(self.basis(xs.shape[0], h2, w2, xs.device), L)
+        return K_xy @ ops.spd_solve(K_yy, self.basis(xs.shape[0], h2, w2, xs.device).contiguous())
 
 
 # ------------------------------------------------------------------------------------------------

@@ -238,6 +238,41 @@ def cos_kernel(x, y, T=0.2, eps=1e-6, diag_add=0.0):
     return K
 
 
+def spd_solve(K, F, nb=64):
+    """Solve K X = F for a batch of SPD matrices by a hand-blocked Cholesky: K (B,n,n) fp32 (DESTROYED: its lower triangle
+    becomes L), F (B,n,m) fp32.  Diagonal blocks are factored (and their factors inverted) by roma_chol_diag_block; panels,
+    trailing updates and the two substitutions are GEMMs.  Replaces `inv(K) @ F` of GP.forward (matcher.py:259-263)."""
+    _need_gpu(K, F)
+    assert K.dtype == torch.float32 and F.dtype == torch.float32 and K.is_contiguous()
+    B, n, _ = K.shape
+    lib = _lib.load()
+    steps = [(j, min(j + nb, n)) for j in range(0, n, nb)]
+    W = torch.empty((B, len(steps), nb, nb), dtype=torch.float32, device=K.device)
+    info = torch.zeros((B,), dtype=torch.int32, device=K.device)
+    for s, (j, e) in enumerate(steps):
+        w = e - j
+        Ajj = K[:, j:e, j:e]
+        check(lib.roma_chol_diag_block(Ajj.data_ptr(), K.stride(1), K.stride(0), W[:, s].data_ptr(), nb, W.stride(0), w, B,
+                                       info.data_ptr(), _stream()), "roma_chol_diag_block")
+        if e < n:
+            P = torch.bmm(K[:, e:, j:e], W[:, s, :w, :w].transpose(1, 2))
+            K[:, e:, j:e] = P
+            K[:, e:, e:].baddbmm_(P, P.transpose(1, 2), alpha=-1.0)
+    X = F.clone()
+    for s, (j, e) in enumerate(steps):                       # L Y = F
+        w = e - j
+        X[:, j:e] = torch.bmm(W[:, s, :w, :w], X[:, j:e])
+        if e < n:
+            X[:, e:].baddbmm_(K[:, e:, j:e], X[:, j:e], alpha=-1.0)
+    for s in range(len(steps) - 1, -1, -1):                  # L^T X = Y
+        j, e = steps[s]
+        w = e - j
+        X[:, j:e] = torch.bmm(W[:, s, :w, :w].transpose(1, 2), X[:, j:e])
+        if j > 0:
+            X[:, :j].baddbmm_(K[:, j:e, :j].transpose(1, 2), X[:, j:e], alpha=-1.0)
+    return X
+
+
 def match_finalize(flow, certainty, cert16, symmetric=True):
     """match() post-processing — matcher.py:656-662, 684-718.  Returns warp (P,H,2W|W,4), certainty (P,H,2W|W)."""
     _need_gpu(flow, certainty, cert16)

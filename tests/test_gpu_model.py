@@ -111,6 +111,29 @@ def test_end_to_end_560_coarse_only_fp32(full_model):
     assert frac < 2e-3 and float(dc.max()) < 2e-3
 
 
+def test_end_to_end_full_560_to_864_fp32(full_model):
+    """BASELINE.json configs[1] on the real pair: full coarse-to-fine 560 -> 864, fp32 mode, against the reference's
+    own output (tests/golden/e2e_864.npz, every 6th pixel + checksums)."""
+    g = H.golden("e2e_864")
+    _set_dtype(full_model, torch.float32)
+    full_model.h_resized = full_model.w_resized = 560
+    full_model.upsample_res = (864, 864)
+    try:
+        warp, cert = full_model.match(H.asset("sacre_coeur_A.jpg"), H.asset("sacre_coeur_B.jpg"), device=DEV)
+    finally:
+        full_model.h_resized = full_model.w_resized = 112
+        full_model.upsample_res = (168, 168)
+    assert warp.shape == (864, 1728, 4) and cert.shape == (864, 1728)
+    dw = (warp.cpu()[::6, ::6] - H.T(g["warp_sample"])).abs()
+    dc = (cert.cpu()[::6, ::6] - H.T(g["cert_sample"])).abs()
+    frac_w, frac_c = float((dw > 1e-3).float().mean()), float((dc > 1e-3).float().mean())
+    print(f"560->864 fp32: warp max {float(dw.max()):.2e} frac>1e-3 {frac_w:.2e}; cert max {float(dc.max()):.2e} frac>1e-3 {frac_c:.2e}")
+    # the arg-max over 4096 anchor classes is a hard discontinuity (SURVEY §7): a flipped coarse pixel moves a whole
+    # neighbourhood, so the full-size check is max-abs where no flip happened plus a bound on the flipped fraction
+    assert frac_w < 2e-3 and frac_c < 2e-2
+    assert float(dw.median()) < 1e-5 and float(dc.median()) < 1e-4
+
+
 def test_end_to_end_fp16_mode_bulk_agreement(full_model):
     g = H.golden("e2e_112")
     _set_dtype(full_model, torch.float16)

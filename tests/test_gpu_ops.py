@@ -214,6 +214,17 @@ def test_cos_kernel_full_size_asymmetric_and_diag():
     assert maxerr(kyy, O.cos_kernel(y, y) + 0.1 * torch.eye(1600)[None]) < 6e-6
 
 
+def test_spd_solve_against_fp64():
+    torch.manual_seed(0)
+    for n, m in ((1600, 512), (100, 16), (54, 32), (65, 8)):
+        x = torch.nn.functional.normalize(torch.randn(2, n, 64), dim=-1)
+        K = torch.exp((x @ x.transpose(1, 2) - 1) / 0.2) + 0.1 * torch.eye(n)
+        F = torch.randn(2, n, m)
+        ref = torch.linalg.solve(K.double(), F.double())
+        X = _ops().spd_solve(K.to(DEV).contiguous(), F.to(DEV))
+        assert float((X.cpu().double() - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+
+
 # ---- match_finalize / kde ----------------------------------------------------------------------
 def test_match_finalize_golden():
     g = H.golden("match_post")
