@@ -11,6 +11,7 @@
 // LDS, and every thread (pixel p, position group g) accumulates its NPOS dot products from LDS with packed dot2
 // (fp16/bf16) or fma (fp32), fp32 accumulation.  D is exchanged through LDS for the 4-tap blend and written out
 // coalesced.  Tiles whose bounding box does not fit in LDS (incoherent flow) read f1 rows straight from L2/HBM.
+#include <type_traits>
 #include "common.h"
 
 namespace roma {
@@ -283,28 +284,32 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned char* lds_wave_
 #endif
 }
 
+constexpr int pow2_floor(int v) { return v >= 16 ? 16 : v >= 8 ? 8 : v >= 4 ? 4 : v >= 2 ? 2 : 1; }
+
 template <typename T, int R>
-__global__ __launch_bounds__(kThreads) void local_corr_nhwc_kernel(LCParams p) {
+__global__ __launch_bounds__(kThreads, 4) void local_corr_nhwc_kernel(LCParams p) {   // <= 128 VGPRs: 4 workgroups / CU
   using G = LCFast<R>;
   constexpr int TW = G::TW, TH = G::TH, TP = G::TP;
   constexpr int N1 = 2 * R + 1, N2 = 2 * R + 2, Q = N2 * N2, K = N1 * N1;
   constexpr int NPIX = TP / 16;                 // pixels handled (one after the other) by each 16-lane group
   constexpr int NIT = (Q + 15) / 16;            // window positions per lane and pixel
+  constexpr int QP = NIT * 16;                  // rows of one per-pixel patch (mode B)
   constexpr int E16 = ElemTraits<T>::kPer16B;
   constexpr int PK = 4, CC = PK * E16;
   constexpr int MAXR = G::MAXR;
-  constexpr int NROWS = TP + MAXR;              // f0 rows + staged box
+  constexpr int SB = pow2_floor(MAXR / QP);     // pixels whose private patches fit in LDS together (mode B)
+  constexpr int NROWS = TP + MAXR;              // f0 rows + staged rows
   constexpr int NL = (NROWS * PK + kThreads - 1) / kThreads;   // DMA rounds (64 rows each)
   constexpr int ZROW = NL * (kThreads / PK);    // 16 all-zero rows right after the DMA'd buffer (never a DMA target)
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u32x4* s_rows = reinterpret_cast<u32x4*>(smem);             // row r, packet k at s_rows[swz(r, k)]
-  int* s_meta = reinterpret_cast<int*>(s_rows + NL * kThreads + 16 * PK);
+  float* s_D = reinterpret_cast<float*>(s_rows + NL * kThreads + 16 * PK);   // [TP][Q+1] integer-grid dot products
+  int* s_meta = reinterpret_cast<int*>(s_D + TP * (Q + 1));
   int* s_x0 = s_meta + 8;
   int* s_y0 = s_x0 + TP;
   float* s_ax = reinterpret_cast<float*>(s_y0 + TP);
   float* s_ay = s_ax + TP;
-  float* s_D = reinterpret_cast<float*>(s_rows);              // aliased after the channel loop: [TP][Q+1]
 
   const int tid = threadIdx.x;
   const int ntile = p.tiles_x * p.tiles_y;
@@ -315,6 +320,7 @@ __global__ __launch_bounds__(kThreads) void local_corr_nhwc_kernel(LCParams p) {
   const int H = p.H, W = p.W;
 
   if (tid < 4) s_meta[tid] = (tid < 2) ? 0x7fffffff : -0x7fffffff;
+  for (int i = tid; i < 16 * PK; i += kThreads) s_rows[ZROW * PK + i] = u32x4{0, 0, 0, 0};
   __syncthreads();
   if (tid < TP) {
     const int y = ty0 + tid / TW, x = tx0 + tid % TW;
@@ -357,9 +363,9 @@ __global__ __launch_bounds__(kThreads) void local_corr_nhwc_kernel(LCParams p) {
   const int bw = empty ? 0 : s_meta[2] - bx0 + 1, bh = empty ? 0 : s_meta[3] - by0 + 1;
   // LDS row pitch of the box: smallest value >= bw congruent to (2r+2) mod 16 (a full 16-wide window needs none)
   const int bwp = (empty || N2 == 16) ? bw : bw + ((N2 - bw) & 15);
-  const int nrows = bwp * bh;
-  const bool staged = nrows <= MAXR;
-  constexpr int zero_row = ZROW;
+  // mode A: the whole tile shares one staged box (coherent flow).  mode B: the box is too large (incoherent flow):
+  // SB pixels at a time get a private (2r+2)^2 patch each (16-row aligned), several passes.
+  const bool modeA = bwp * bh <= MAXR;
 
   // 16-lane ds_read_b128 service groups of a wavefront: {0-3,12-15,20-27}, {4-11,16-19,28-31}, and the same +32
   int g16, idx;
@@ -376,119 +382,109 @@ __global__ __launch_bounds__(kThreads) void local_corr_nhwc_kernel(LCParams p) {
   }
   const T* f0 = static_cast<const T*>(p.f0) + (size_t)b * H * W * p.f0_pitch;
   const T* f1 = static_cast<const T*>(p.f1) + (size_t)b * H * W * p.f1_pitch;
-  float acc[NPIX][NIT];
-#pragma unroll
-  for (int a = 0; a < NPIX; ++a)
-#pragma unroll
-    for (int i = 0; i < NIT; ++i) acc[a][i] = 0.f;
 
-  if (staged) {
-    // LDS offsets (in packets, before the per-k swizzle) of this lane's window rows
-    int rowidx[NPIX][NIT];
+  // The two modes are separate instantiations of one lambda so that each keeps its own (small) register set.
+  // A work item = 16 consecutive window positions (one "iteration" it) of one pixel, reduced by one 16-lane group.
+  //   mode A: group g16 owns pixels a*16+g16 and all NIT iterations of each               -> NPIX*NIT items
+  //   mode B: the SB*NIT items of the pass are dealt round-robin to the 16 groups           -> UB items
+  auto run = [&](auto mode_tag) {
+    constexpr bool MA = decltype(mode_tag)::value;
+    constexpr int UB = (SB * NIT + 15) / 16;
+    constexpr int WN = MA ? NPIX * NIT : UB;
+    const int npasses = MA ? 1 : (TP + SB - 1) / SB;
+    for (int pass = 0; pass < npasses; ++pass) {
+      int pixw[WN], qw[WN], rowidx[WN];
+      float acc[WN];
 #pragma unroll
-    for (int a = 0; a < NPIX; ++a) {
-      const int pix = a * 16 + g16;
-      const bool pvalid = (ty0 + pix / TW < H) && (tx0 + pix % TW < W);
-      const int px0 = s_x0[pix], py0 = s_y0[pix];
-#pragma unroll
-      for (int i = 0; i < NIT; ++i) {
-        const int q = i * 16 + idx;
-        const int yy = py0 - R + q / N2, xx = px0 - R + q % N2;
-        const bool ok = pvalid && (q < Q) && (yy >= 0) && (yy < H) && (xx >= 0) && (xx < W);
-        rowidx[a][i] = ok ? TP + (yy - by0) * bwp + (xx - bx0) : zero_row;
-      }
-    }
-    for (int i = tid; i < 16 * PK; i += kThreads) s_rows[ZROW * PK + i] = u32x4{0, 0, 0, 0};
-    // ---- DMA plan: LDS packet slot s = l*256 + tid holds (row = s/4, k = (s%4) ^ ((row>>2)&3)); its global source is
-    // fixed for the whole channel loop.  Slots that hold nothing (pitch padding, rows beyond the box) read a valid dummy
-    // address and are never consumed. ----
-    const T* src[NL];
-    const int used_rows = TP + nrows;
-#pragma unroll
-    for (int l = 0; l < NL; ++l) {
-      const int slot = l * kThreads + tid;
-      const int row = slot >> 2;
-      const int k = (slot & 3) ^ ((row >> 2) & 3);
-      int y = ty0, x = tx0, pitch = p.f0_pitch;
-      const T* base = f0;
-      if (row < TP) {
-        y = min(ty0 + row / TW, H - 1);
-        x = min(tx0 + row % TW, W - 1);
-      } else if (row < used_rows) {
-        const int rr = row - TP;
-        const int ry = rr / bwp, rx = rr - ry * bwp;
-        if (rx < bw) {
-          y = by0 + ry;
-          x = bx0 + rx;
-          base = f1;
-          pitch = p.f1_pitch;
+      for (int w = 0; w < WN; ++w) {
+        int pix, it, slot = 0;
+        if (MA) {
+          pix = (w / NIT) * 16 + g16;
+          it = w % NIT;
+        } else {
+          const int u = g16 + 16 * w;
+          slot = u / NIT;
+          it = u - slot * NIT;
+          pix = (u < SB * NIT) ? pass * SB + slot : TP;
         }
+        const bool pact = pix < TP;
+        pix = pact ? pix : 0;
+        const bool pvalid = pact && (ty0 + pix / TW < H) && (tx0 + pix % TW < W);
+        const int q = it * 16 + idx;
+        const int yy = s_y0[pix] - R + q / N2, xx = s_x0[pix] - R + q % N2;
+        const bool ok = pvalid && (q < Q) && (yy >= 0) && (yy < H) && (xx >= 0) && (xx < W);
+        const int row = MA ? TP + (yy - by0) * bwp + (xx - bx0) : TP + slot * QP + q;
+        pixw[w] = pvalid ? pix : -1;
+        qw[w] = q;
+        rowidx[w] = ok ? row : ZROW;
+        acc[w] = 0.f;
       }
-      src[l] = base + ((size_t)y * W + x) * pitch + k * E16;
-    }
-    const int nl_used = (((used_rows + 15) & ~15) * PK + kThreads - 1) / kThreads;   // DMA rounds that carry data
-
-    for (int c0 = 0; c0 < p.C; c0 += CC) {
+      // ---- DMA plan: LDS packet slot s = l*256 + tid holds (row = s/4, k = (s%4) ^ ((row>>2)&3)); its global source
+      // is fixed for the whole channel loop.  Slots that hold nothing read a valid dummy address, never consumed. ----
+      const T* src[NL];
+      const int used_rows = TP + (MA ? bwp * bh : SB * QP);
 #pragma unroll
-      for (int l = 0; l < NL; ++l)
-        if (l < nl_used)
-          dma16(src[l] + c0, smem + (size_t)(l * kThreads + (tid & ~63)) * 16);
-      __syncthreads();                                          // vmcnt(0) + barrier: the chunk has landed
+      for (int l = 0; l < NL; ++l) {
+        const int slot = l * kThreads + tid;
+        const int row = slot >> 2;
+        const int k = (slot & 3) ^ ((row >> 2) & 3);
+        int y = ty0, x = tx0, pitch = p.f0_pitch;
+        const T* base = f0;
+        if (row < TP) {
+          y = min(ty0 + row / TW, H - 1);
+          x = min(tx0 + row % TW, W - 1);
+        } else if (row < used_rows) {
+          const int rr = row - TP;
+          if (MA) {
+            const int ry = rr / bwp, rx = rr - ry * bwp;
+            if (rx < bw) {
+              y = by0 + ry;
+              x = bx0 + rx;
+              base = f1;
+              pitch = p.f1_pitch;
+            }
+          } else {
+            const int sl = rr / QP, q = rr - sl * QP;
+            const int pix = pass * SB + sl;
+            if (pix < TP && q < Q) {
+              y = min(max(s_y0[pix] - R + q / N2, 0), H - 1);
+              x = min(max(s_x0[pix] - R + q % N2, 0), W - 1);
+              base = f1;
+              pitch = p.f1_pitch;
+            }
+          }
+        }
+        src[l] = base + ((size_t)y * W + x) * pitch + k * E16;
+      }
+      const int nl_used = (((used_rows + 15) & ~15) * PK + kThreads - 1) / kThreads;   // DMA rounds that carry data
+      for (int c0 = 0; c0 < p.C; c0 += CC) {
 #pragma unroll
-      for (int a = 0; a < NPIX; ++a) {
-        const int prow = a * 16 + g16;
+        for (int l = 0; l < NL; ++l)
+          if (l < nl_used) dma16(src[l] + c0, smem + (size_t)(l * kThreads + (tid & ~63)) * 16);
+        __syncthreads();                                        // vmcnt(0) + barrier: the chunk has landed
         u32x4 fa[PK];
 #pragma unroll
-        for (int k = 0; k < PK; ++k) fa[k] = s_rows[swz(prow, k)];                      // broadcast within the group
+        for (int w = 0; w < WN; ++w) {
+          if (!MA || w % NIT == 0) {                            // the pixel's own f0 row: broadcast within the group
+            const int prow = pixw[w] < 0 ? 0 : pixw[w];
 #pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-          const int r0 = rowidx[a][i];
+            for (int k = 0; k < PK; ++k) fa[k] = s_rows[swz(prow, k)];
+          }
+          const int r0 = rowidx[w];
           const int sw = (r0 >> 2) & 3;
-          float sacc = acc[a][i];
+          float sacc = acc[w];
 #pragma unroll
           for (int k = 0; k < PK; ++k) sacc = dot16<T>(fa[k], s_rows[r0 * 4 + (k ^ sw)], sacc);
-          acc[a][i] = sacc;
+          acc[w] = sacc;
         }
+        __syncthreads();                                        // everyone is done reading before the next DMA lands
       }
-      __syncthreads();                                          // everyone is done reading before the next DMA lands
+#pragma unroll
+      for (int w = 0; w < WN; ++w)
+        if (qw[w] < Q && pixw[w] >= 0) s_D[pixw[w] * (Q + 1) + qw[w]] = acc[w] * p.scale;
     }
-  } else {
-    // incoherent tile: every (pixel, position) row straight from L2/HBM; correct for any flow, not the fast path
-#pragma unroll
-    for (int a = 0; a < NPIX; ++a) {
-      const int pix = a * 16 + g16;
-      const int y = ty0 + pix / TW, x = tx0 + pix % TW;
-      const bool pvalid = (y < H) && (x < W);
-      const int px0 = s_x0[pix], py0 = s_y0[pix];
-#pragma unroll 1
-      for (int c0 = 0; c0 < p.C; c0 += CC) {
-        u32x4 fa[PK];
-#pragma unroll
-        for (int k = 0; k < PK; ++k)
-          fa[k] = *reinterpret_cast<const u32x4*>(f0 + ((size_t)min(y, H - 1) * W + min(x, W - 1)) * p.f0_pitch + c0 + k * E16);
-#pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-          const int q = i * 16 + idx;
-          const int yy = py0 - R + q / N2, xx = px0 - R + q % N2;
-          const bool ok = pvalid && (q < Q) && (yy >= 0) && (yy < H) && (xx >= 0) && (xx < W);
-          const T* rsrc = f1 + ((size_t)min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1)) * p.f1_pitch + c0;
-          float sacc = 0.f;
-#pragma unroll
-          for (int k = 0; k < PK; ++k) sacc = dot16<T>(fa[k], *reinterpret_cast<const u32x4*>(rsrc + k * E16), sacc);
-          acc[a][i] += ok ? sacc : 0.f;
-        }
-      }
-    }
-    __syncthreads();
-  }
-
-#pragma unroll
-  for (int a = 0; a < NPIX; ++a)
-#pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-      const int q = i * 16 + idx;
-      if (q < Q) s_D[(a * 16 + g16) * (Q + 1) + q] = acc[a][i] * p.scale;
-    }
+  };
+  if (modeA) run(std::true_type{}); else run(std::false_type{});
   __syncthreads();
   T* out = static_cast<T*>(p.out);
   for (int e = tid; e < TP * K; e += kThreads) {
@@ -514,12 +510,9 @@ int launch_lc_nhwc(LCParams p, hipStream_t stream) {
   p.tiles_x = (p.W + G::TW - 1) / G::TW;
   p.tiles_y = (p.H + G::TH - 1) / G::TH;
   p.max_rows = G::MAXR;
-  size_t body = (size_t)NL * kThreads * 16 + 16 * 4 * 16;      // DMA'd rows + 16 zero rows
-  const size_t need_D = (size_t)TP * (Q + 1) * 4;
-  if (body < need_D) body = need_D;
-  const size_t meta = (8 + 2 * TP) * 4 + 2 * TP * 4;
-  static_assert((size_t)NL * kThreads * 16 >= (size_t)TP * (Q + 1) * 4, "D exchange must fit in the row buffer");
-  const size_t smem = body + meta;
+  const size_t smem = (size_t)NL * kThreads * 16 + 16 * 4 * 16      // DMA'd rows + 16 zero rows
+                      + (size_t)TP * (Q + 1) * 4                     // D exchange
+                      + (8 + 2 * TP) * 4 + 2 * TP * 4;              // meta
   const int grid = p.B * p.tiles_x * p.tiles_y;
   hipLaunchKernelGGL((local_corr_nhwc_kernel<T, R>), dim3(grid), dim3(kThreads), smem, stream, p);
   ROMA_CHECK_LAUNCH();
