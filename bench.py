@@ -41,13 +41,6 @@ def build_model(device, dtype):
     return model.to(device).eval()
 
 
-def set_dtype(model, dt):
-    model.encoder.amp_dtype = dt
-    model.decoder.amp_dtype = dt
-    for r in model.decoder.conv_refiner.values():
-        r.amp_dtype = dt
-
-
 def host_cores():
     """CPU threads this process may really use: cgroup quota / affinity mask, not the host's core count."""
     n = os.cpu_count() or 1
@@ -64,7 +57,10 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("ROMA_BENCH_CPU_THREADS", "16"))))
 
 
-def cpu_baseline(gpu_fp32_result, budget_s=240):
+PARITY_IMAGES = [os.path.join(ROOT, "tests", "golden", "assets", f"sacre_coeur_{n}.jpg") for n in "AB"]
+
+
+def cpu_baseline(gpu_fp32_result, budget_s=240, images=None):
     """The oracle (CPU port of the reference path, oracle/roma_oracle.py) on ONE full 560->864 pair on the box's host
     cores, in a fresh CPU-only child process (oracle/cpu_baseline.py) with a hard time budget; also the parity gate."""
     import subprocess
@@ -75,22 +71,74 @@ def cpu_baseline(gpu_fp32_result, budget_s=240):
     log(f"[bench] cpu_baseline: oracle 560->864, {cores} threads, budget {budget_s}s ...")
     env = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
     try:
-        subprocess.run([sys.executable, "-m", "oracle.cpu_baseline", "--out", out, "--threads", str(cores)], cwd=ROOT, env=env,
-                       check=True, timeout=budget_s)
+        cmd = [sys.executable, "-m", "oracle.cpu_baseline", "--out", out, "--threads", str(cores)]
+        if images:
+            cmd += ["--images"] + list(images)
+        subprocess.run(cmd, cwd=ROOT, env=env, check=True, timeout=budget_s)
     except (subprocess.TimeoutExpired, subprocess.CalledProcessError) as e:
         log(f"[bench] cpu_baseline did not finish: {e!r}")
         return None, None
     meta = json.load(open(os.path.join(out, "cpu_baseline.json")))
+    what = "the sacre_coeur photograph pair (tests/golden/assets)" if images else "1 synthetic pair"
     res = {"value": 1.0 / meta["seconds"], "unit": "image-pairs/s", "cores": meta["threads"], "kind": "port",
-           "sample": f"1 synthetic pair, full 560->864 symmetric match, oracle/roma_oracle.py fp32, {meta['seconds']:.1f} s"}
+           "sample": f"{what}, full 560->864 symmetric match, oracle/roma_oracle.py fp32, {meta['seconds']:.1f} s"}
     parity = None
     if gpu_fp32_result is not None:
         gw, gc = gpu_fp32_result
         dw = (gw.cpu()[0] - torch.from_numpy(np.load(os.path.join(out, "warp.npy")))[0]).abs()
         dc = (gc.cpu()[0] - torch.from_numpy(np.load(os.path.join(out, "certainty.npy")))[0]).abs()
-        parity = {"mode": "fp32", "warp_max_abs": float(dw.max()), "certainty_max_abs": float(dc.max()),
+        parity = {"mode": "fp32", "inputs": "sacre_coeur_A/B.jpg" if images else "synthetic pair 0", "warp_max_abs": float(dw.max()), "certainty_max_abs": float(dc.max()),
                   "warp_frac_gt_1e-3": float((dw > 1e-3).float().mean()), "tolerance": 1e-3}
     return res, parity
+
+
+LC_SHAPES = [("L16", 512, 40, 7), ("L8", 512, 70, 3), ("L4", 256, 140, 2), ("U8", 512, 108, 3), ("U4", 256, 216, 2)]
+
+
+def local_corr_microbench(device, dtype, pairs, iters=20):
+    """SURVEY §8(d) Metric 2: the same kernel on the five 560->864 call shapes with the prescribed COHERENT flow
+    (identity grid o affine(rot 10 deg, scale 1.1, shift 0.05) + N(0, (0.5 px)^2)) and with U(-1.2,1.2) (adversarial
+    floor).  A trained matcher produces coherent flow; random-init weights (what the timed pipeline runs) do not."""
+    import math
+    from roma_amd import ops
+    es = 4 if dtype == torch.float32 else 2
+    B = 2 * pairs
+    out = {}
+    g = torch.Generator().manual_seed(0)
+    for kind in ("coherent", "adversarial"):
+        tot_b = tot_t = 0.0
+        per = {}
+        for name, C, h, r in LC_SHAPES:
+            K = (2 * r + 1) ** 2
+            f0 = torch.randn(B, C, h, h, generator=g).to(device=device, dtype=dtype).contiguous(memory_format=torch.channels_last)
+            f1 = torch.randn(B, C, h, h, generator=g).to(device=device, dtype=dtype).contiguous(memory_format=torch.channels_last)
+            if kind == "coherent":
+                ys = torch.linspace(-1 + 1 / h, 1 - 1 / h, h)
+                gx, gy = ys[None, :].expand(h, h), ys[:, None].expand(h, h)
+                c, s_ = math.cos(math.radians(10)) * 1.1, math.sin(math.radians(10)) * 1.1
+                flow = torch.stack((c * gx - s_ * gy + 0.05, s_ * gx + c * gy - 0.05))[None].expand(B, 2, h, h)
+                flow = flow + torch.randn(B, 2, h, h, generator=g) * (0.5 * 2 / h)
+            else:
+                flow = torch.rand(B, 2, h, h, generator=g) * 2.4 - 1.2
+            flow = flow.contiguous().to(device)
+            o = ops.nhwc_empty(B, K, h, h, dtype, device)
+            for _ in range(3):
+                ops.local_correlation(f0, f1, r, flow=flow, out=o)
+            torch.cuda.synchronize()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(iters):
+                ops.local_correlation(f0, f1, r, flow=flow, out=o)
+            e.record()
+            torch.cuda.synchronize()
+            t = s.elapsed_time(e) / iters * 1e-3
+            nb = 2 * B * C * h * h * es + B * 2 * h * h * 4 + B * K * h * h * es
+            per[name] = {"us": t * 1e6, "GB/s": nb / t / 1e9}
+            tot_b += nb
+            tot_t += t
+        out[kind] = {"achieved": tot_b / tot_t / 1e9, "frac": tot_b / tot_t / HBM_PEAK, "unit": "GB/s", "per_shape": per}
+    out["note"] = "standalone launches of local_corr_kernel on the 5 call shapes, B=%d, same process, after the timed region" % B
+    return out
 
 
 def main():
@@ -172,13 +220,26 @@ def main():
             pmc = os.path.join(ROOT, "profiles", "local_corr_traffic.json")
             if os.path.exists(pmc):          # HBM bytes per launch from a separate rocprofv3 --pmc pass (see profiles/README.md)
                 roof["traffic"] = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        micro = local_corr_microbench(device, dtype, P)
         cpu = parity = None
         if do_cpu:
-            set_dtype(model, torch.float32)
-            g32 = model.match_tensors(A_lo[:1], B_lo[:1], A_hi[:1], B_hi[:1])
+            # parity gate + CPU baseline on a real photograph pair when the fixture images are present (the decoder's
+            # arg-max makes near-tied synthetic textures flip coarse pixels between ANY two fp32 implementations)
+            images = PARITY_IMAGES if all(os.path.exists(f) for f in PARITY_IMAGES) else None
+            if images:
+                from PIL import Image
+                from roma_amd.matcher import preprocess
+                ims = [Image.open(f).convert("RGB") for f in images]
+                pin = [preprocess(im, (560, 560))[None].to(device) for im in ims] + [preprocess(im, (864, 864))[None].to(device) for im in ims]
+            else:
+                pin = [A_lo[:1], B_lo[:1], A_hi[:1], B_hi[:1]]
+            del model                                    # its ViT weights were cast to the amp dtype in place
+            torch.cuda.empty_cache()
+            model32 = build_model(device, torch.float32)
+            g32 = model32.match_tensors(*pin)
             torch.cuda.synchronize()
-            set_dtype(model, dtype)
-            cpu, parity = cpu_baseline(g32)
+            del model32
+            cpu, parity = cpu_baseline(g32, images=images)
         total_pairs = world * P * args.steps
         line = {
             "metric": "image-pairs/sec at 560->864", "value": total_pairs / elapsed, "unit": "image-pairs/s",
@@ -187,7 +248,7 @@ def main():
             "config": {"workload": "roma_outdoor 560->864 full coarse-to-fine symmetric match, random-init weights",
                        "pairs_per_gpu_per_step": P, "global_pairs_per_step": world * P, "coarse_res": 560, "upsample_res": 864,
                        "parallelism": f"pair-sharded x{world}, gather of (warp, certainty) to rank 0" if world > 1 else "single GPU"},
-            "roofline": roof, "cpu_baseline": cpu, "parity": parity,
+            "roofline": roof, "roofline_microbench": micro, "cpu_baseline": cpu, "parity": parity,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

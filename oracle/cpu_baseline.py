@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--hi", type=int, default=864)
     ap.add_argument("--pair", type=int, default=0)
     ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--images", nargs=2, default=None, help="two image files: match this real pair instead of a synthetic one")
     a = ap.parse_args()
     if a.threads:
         os.environ["OMP_NUM_THREADS"] = str(a.threads)
@@ -38,7 +39,12 @@ def main():
     m = O.roma_model((a.lo, a.lo), (a.hi, a.hi))
     load_synthetic_weights(m, seed=0)
     m.encoder.dinov2_vitl14[0].eval()
-    pair = synthetic_pair(a.pair, (a.lo, a.lo), (a.hi, a.hi))
+    if a.images:
+        from PIL import Image
+        ims = [Image.open(f).convert("RGB") for f in a.images]
+        pair = [O.preprocess(im, (a.lo, a.lo))[None] for im in ims] + [O.preprocess(im, (a.hi, a.hi))[None] for im in ims]
+    else:
+        pair = synthetic_pair(a.pair, (a.lo, a.lo), (a.hi, a.hi))
     build_s = time.time() - t0
     print(f"[cpu_baseline] model built in {build_s:.1f}s, {torch.get_num_threads()} threads; matching ...", file=sys.stderr, flush=True)
     t0 = time.time()

@@ -1,6 +1,6 @@
 """Deterministic synthetic weights and image pairs for bench.py / smoke() (no datasets or checkpoints offline).
-Variance-preserving random parameters (N(0, 1/fan_in) weights, non-trivial BatchNorm statistics), generated on the
-CPU with a seeded torch.Generator so that every rank and the CPU oracle hold bit-identical values."""
+Variance-preserving random parameters (N(0, 1/fan_in) weights, non-trivial BatchNorm statistics), a pure function of
+(parameter name, shape, seed) so that every rank and the CPU oracle hold bit-identical values."""
 from __future__ import annotations
 
 import math
@@ -8,37 +8,44 @@ import math
 import torch
 
 
+def _rs(name: str, seed: int):
+    import zlib
+    import numpy as np
+    return np.random.RandomState((zlib.crc32(name.encode()) ^ (seed * 2654435761)) & 0x7FFFFFFF)
+
+
+def synthetic_tensor(key: str, shape, seed: int = 0, gains: dict | None = None) -> torch.Tensor:
+    """One state-dict entry, a function of (key, shape, seed) only (numpy RandomState: bit-stable everywhere).
+    Same recipe as the parity tests use (tests/golden/recipes.py), so bench.py and the tests run the same model."""
+    import numpy as np
+    shape = tuple(int(s) for s in shape)
+    gain = 1.0
+    for pat, g in (gains or {}).items():
+        if pat in key:
+            gain = g
+    last = key.rsplit(".", 1)[-1]
+    rs = _rs(key, seed)
+    if last == "num_batches_tracked":
+        return torch.zeros(shape, dtype=torch.int64)
+    if last == "running_var":
+        a = rs.uniform(0.5, 1.5, size=shape)
+    elif last == "running_mean":
+        a = rs.standard_normal(size=shape) * 0.1
+    elif last == "gamma":
+        a = rs.uniform(0.5, 1.5, size=shape)
+    elif last in ("cls_token", "pos_embed", "mask_token"):
+        a = rs.standard_normal(size=shape) * 0.02
+    elif last == "bias":
+        a = rs.standard_normal(size=shape) * (0.05 * gain)
+    elif len(shape) == 1:
+        a = rs.uniform(0.5, 1.5, size=shape)
+    else:
+        a = rs.standard_normal(size=shape) * (gain / math.sqrt(float(np.prod(shape[1:]))))
+    return torch.from_numpy(a.astype(np.float32))
+
+
 def synthetic_state_dict(shapes: dict, seed: int = 0, gains: dict | None = None) -> dict:
-    g = torch.Generator().manual_seed(seed)
-    out = {}
-    for k in sorted(shapes):
-        shape = tuple(shapes[k])
-        last = k.rsplit(".", 1)[-1]
-        gain = 1.0
-        for pat, v in (gains or {}).items():
-            if pat in k:
-                gain = v
-        if last == "num_batches_tracked":
-            t = torch.zeros(shape, dtype=torch.int64)
-        elif last == "running_var":
-            t = torch.rand(shape, generator=g) + 0.5
-        elif last == "running_mean":
-            t = torch.randn(shape, generator=g) * 0.1
-        elif last == "gamma":
-            t = torch.rand(shape, generator=g) + 0.5
-        elif last in ("cls_token", "pos_embed", "mask_token"):
-            t = torch.randn(shape, generator=g) * 0.02
-        elif last == "bias":
-            t = torch.randn(shape, generator=g) * 0.05 * gain
-        elif len(shape) == 1:
-            t = torch.rand(shape, generator=g) + 0.5
-        else:
-            fan_in = 1
-            for s in shape[1:]:
-                fan_in *= s
-            t = torch.randn(shape, generator=g) * (gain / math.sqrt(fan_in))
-        out[k] = t
-    return out
+    return {k: synthetic_tensor(k, s, seed, gains) for k, s in shapes.items()}
 
 
 SYNTH_GAINS = {"to_out": 6.0, "pos_conv": 4.0}
@@ -47,8 +54,7 @@ SYNTH_GAINS = {"to_out": 6.0, "pos_conv": 4.0}
 def load_synthetic_weights(model, seed: int = 0):
     """Fill a roma model (product or oracle: same key layout) and its DINOv2 trunk in place."""
     vit = model.encoder.dinov2_vitl14[0]
-    sd = synthetic_state_dict({k: v.shape for k, v in model.state_dict().items()}, seed, SYNTH_GAINS)
-    model.load_state_dict(sd)
+    model.load_state_dict(synthetic_state_dict({k: v.shape for k, v in model.state_dict().items()}, seed, SYNTH_GAINS))
     vd = synthetic_state_dict({"dinov2." + k: v.shape for k, v in vit.state_dict().items()}, seed)
     vit.load_state_dict({k[len("dinov2."):]: v for k, v in vd.items()})
     return model
