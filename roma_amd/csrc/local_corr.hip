@@ -518,6 +518,335 @@ int launch_lc_nhwc(LCParams p, hipStream_t stream) {
   ROMA_CHECK_LAUNCH();
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// fp16 / bf16 channels-last path on the matrix cores.
+// PMC showed the VALU version issue-bound (2.7x more VALU instructions than the minimum dot2 count), not HBM-bound, so
+// the dot products move to v_mfma_f32_16x16x32_{f16,bf16}: M = the 16 pixels of a 4x4 group, N = 16 horizontally
+// consecutive target positions of one row of the group's union window, K = 32 channels = one 64-byte LDS row chunk.
+// A fragment (the group's f0 rows) is read once per chunk and reused for every block; each B fragment is one
+// ds_read_b128 of 16 consecutive staged rows.  Rows are XOR-swizzled by (row>>2)&1 and the four K-slices are assigned to
+// the lane quarters in the order (0,2,1,3): with the fixed ds_read_b128 lane groups this is bank-conflict free for any
+// row base (exhaustive search, tools/scratch).  The 16x16 results go through LDS (per pixel [row][col] images) for the
+// 4-tap blend.  Only 1/4-1/3 of the computed products are used (every pixel needs (2r+2)^2 of the union's positions),
+// which the 16x MFMA rate absorbs.  Tiles whose groups are not compact (incoherent flow) use per-pixel patches on the
+// VALU (mode B of the kernel above, same staging).
+// ------------------------------------------------------------------------------------------------------------------
+template <int R> struct LCM {
+  static constexpr int NG = R <= 3 ? 2 : 1;                  // 4x4-pixel groups per tile
+  static constexpr int TP = 16 * NG, TW = 4 * NG, TH = 4;
+  static constexpr int WPG = 4 / NG;                         // wavefronts per group
+  static constexpr int N2 = 2 * R + 2;
+  static constexpr int NRUN = N2 <= 10 ? 1 : 2;              // 16-position runs per union row
+  static constexpr int WC = 16 * NRUN;                       // union columns a group may span
+  static constexpr int GHMAX = N2 + 10;                      // union rows a group may span
+  static constexpr int NB = (GHMAX * NRUN + WPG - 1) / WPG;  // accumulator blocks per wavefront
+  static constexpr int MS = GHMAX * WC + 4;                  // floats per pixel in the exchange buffer (= 4 mod 8: no write conflicts)
+  static constexpr int MAXR = R <= 3 ? 384 : 704;            // staged rows
+};
+
+typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 b8_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float4_t mfma16(const u32x4& a, const u32x4& b, float4_t c, half_t) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, a), __builtin_bit_cast(h8_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ float4_t mfma16(const u32x4& a, const u32x4& b, float4_t c, bf16_t) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8_t, a), __builtin_bit_cast(b8_t, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ int swz1(int row, int k) { return row * 4 + (k ^ ((row >> 2) & 1)); }
+
+template <typename T, int R>
+__global__ __launch_bounds__(kThreads, 2) void local_corr_mfma_kernel(LCParams p) {
+  using M = LCM<R>;
+  constexpr int NG = M::NG, TP = M::TP, TW = M::TW, TH = M::TH, WPG = M::WPG, NRUN = M::NRUN, WC = M::WC;
+  constexpr int GHMAX = M::GHMAX, NB = M::NB, MS = M::MS, MAXR = M::MAXR;
+  constexpr int N1 = 2 * R + 1, N2 = 2 * R + 2, Q = N2 * N2, K = N1 * N1;
+  constexpr int NIT = (Q + 15) / 16, QP = NIT * 16;
+  constexpr int E16 = 8, PK = 4, CC = PK * E16;
+  constexpr int SB = pow2_floor(MAXR / QP);
+  constexpr int NL = ((TP + MAXR) * PK + kThreads - 1) / kThreads;
+  constexpr int ZROW = NL * (kThreads / PK);
+  constexpr int BODY16 = (NL * kThreads + 16 * PK) > (NG * 16 * MS / 4 + 1) ? (NL * kThreads + 16 * PK) : (NG * 16 * MS / 4 + 1);
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u32x4* s_rows = reinterpret_cast<u32x4*>(smem);             // staged rows; later the MFMA result exchange S
+  float* s_S = reinterpret_cast<float*>(smem);
+  float* s_D = reinterpret_cast<float*>(s_rows + BODY16);     // [TP][Q+1], mode B only
+  int* s_meta = reinterpret_cast<int*>(s_D + TP * (Q + 1));   // [0..3] tile box, [8+4g ..] group boxes
+  int* s_x0 = s_meta + 8 + 4 * NG;
+  int* s_y0 = s_x0 + TP;
+  float* s_ax = reinterpret_cast<float*>(s_y0 + TP);
+  float* s_ay = s_ax + TP;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ntile = p.tiles_x * p.tiles_y;
+  const int wid = xcd_remap(blockIdx.x, gridDim.x);
+  const int b = wid / ntile;
+  const int t = wid - b * ntile;
+  const int ty0 = (t / p.tiles_x) * TH, tx0 = (t % p.tiles_x) * TW;
+  const int H = p.H, W = p.W;
+
+  if (tid < 8 + 4 * NG) s_meta[tid] = ((tid & 3) < 2) ? 0x7fffffff : -0x7fffffff;
+  for (int i = tid; i < 16 * PK; i += kThreads) s_rows[ZROW * PK + i] = u32x4{0, 0, 0, 0};
+  __syncthreads();
+  if (tid < TP) {
+    const int y = ty0 + tid / TW, x = tx0 + tid % TW;
+    int x0 = 0, y0 = 0;
+    float ax = 0.f, ay = 0.f;
+    if (y < H && x < W) {
+      float fx, fy;
+      if (p.flow) {
+        fx = p.flow[((size_t)(b * 2 + 0) * H + y) * W + x];
+        fy = p.flow[((size_t)(b * 2 + 1) * H + y) * W + x];
+      } else {
+        fx = -1.f + (2.f * x + 1.f) / W;
+        fy = -1.f + (2.f * y + 1.f) / H;
+      }
+      float px = ((fx + 1.f) * W - 1.f) * 0.5f, py = ((fy + 1.f) * H - 1.f) * 0.5f;
+      if (!(px > -1e6f && px < 1e6f)) px = -1e6f;
+      if (!(py > -1e6f && py < 1e6f)) py = -1e6f;
+      const float fx0 = floorf(px), fy0 = floorf(py);
+      ax = px - fx0;
+      ay = py - fy0;
+      x0 = (int)fx0;
+      y0 = (int)fy0;
+      const int lox = max(x0 - R, 0), hix = min(x0 + R + 1, W - 1);
+      const int loy = max(y0 - R, 0), hiy = min(y0 + R + 1, H - 1);
+      if (lox <= hix && loy <= hiy) {
+        int* gm = s_meta + 8 + 4 * ((tid % TW) / 4);
+        atomicMin(&s_meta[0], lox); atomicMin(&s_meta[1], loy); atomicMax(&s_meta[2], hix); atomicMax(&s_meta[3], hiy);
+        atomicMin(&gm[0], lox); atomicMin(&gm[1], loy); atomicMax(&gm[2], hix); atomicMax(&gm[3], hiy);
+      }
+    }
+    s_x0[tid] = x0;
+    s_y0[tid] = y0;
+    s_ax[tid] = ax;
+    s_ay[tid] = ay;
+  }
+  __syncthreads();
+  const int bx0 = s_meta[0], by0 = s_meta[1];
+  const bool empty = s_meta[2] < bx0 || s_meta[3] < by0;
+  const int bw = empty ? 0 : s_meta[2] - bx0 + 1, bh = empty ? 0 : s_meta[3] - by0 + 1;
+  bool eligible = bw * bh <= MAXR;
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const int* gm = s_meta + 8 + 4 * g;
+    if (gm[2] >= gm[0] && gm[3] >= gm[1]) eligible = eligible && (gm[2] - gm[0] + 1 <= WC) && (gm[3] - gm[1] + 1 <= GHMAX);
+  }
+  const T* f0 = static_cast<const T*>(p.f0) + (size_t)b * H * W * p.f0_pitch;
+  const T* f1 = static_cast<const T*>(p.f1) + (size_t)b * H * W * p.f1_pitch;
+  T* out = static_cast<T*>(p.out);
+  // LDS row of pixel (ty,tx)'s f0: group-major so that a group's 16 rows are consecutive (A fragment = one b128 each)
+  auto frow = [&](int pix) { const int ty = pix / TW, tx = pix % TW; return (tx >> 2) * 16 + ty * 4 + (tx & 3); };
+  auto fpix = [&](int row, int& y, int& x) { const int g = row >> 4, m = row & 15; y = ty0 + (m >> 2); x = tx0 + 4 * g + (m & 3); };
+
+  if (eligible) {
+    // =========================== matrix-core path ===========================
+    const T* src[NL];
+    const int used_rows = TP + bw * bh;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      const int slot = l * kThreads + tid;
+      const int row = slot >> 2;
+      const int k = (slot & 3) ^ ((row >> 2) & 1);
+      int y = ty0, x = tx0, pitch = p.f0_pitch;
+      const T* base = f0;
+      if (row < TP) {
+        fpix(row, y, x);
+        y = min(y, H - 1);
+        x = min(x, W - 1);
+      } else if (row < used_rows) {
+        const int rr = row - TP;
+        const int ry = rr / bw;
+        y = by0 + ry;
+        x = bx0 + rr - ry * bw;
+        base = f1;
+        pitch = p.f1_pitch;
+      }
+      src[l] = base + ((size_t)y * W + x) * pitch + k * E16;
+    }
+    const int nl_used = (((used_rows + 15) & ~15) * PK + kThreads - 1) / kThreads;
+    const int gi = wave / WPG, sub = wave % WPG;
+    const int* gm = s_meta + 8 + 4 * gi;
+    const bool gempty = gm[2] < gm[0] || gm[3] < gm[1];
+    const int gx0 = gm[0], gy0 = gm[1];
+    const int gh = gempty ? 0 : gm[3] - gy0 + 1;
+    const int n = lane & 15, kg = lane >> 4;
+    const int ks = (kg == 1) ? 2 : (kg == 2 ? 1 : kg);          // K-slice of this lane quarter: (0,2,1,3)
+    int bidx[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int blk = sub + WPG * j;
+      const int ry = blk / NRUN, run = blk - ry * NRUN;
+      const int row = (blk < gh * NRUN ? TP + (gy0 - by0 + ry) * bw + (gx0 - bx0 + 16 * run) : ZROW) + n;
+      bidx[j] = swz1(row, ks);
+    }
+    const int aidx = swz1(gi * 16 + n, ks);
+    float4_t acc[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) acc[j] = float4_t{0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < p.C; c0 += CC) {
+#pragma unroll
+      for (int l = 0; l < NL; ++l)
+        if (l < nl_used) dma16(src[l] + c0, smem + (size_t)(l * kThreads + (tid & ~63)) * 16);
+      __syncthreads();
+      const u32x4 a = s_rows[aidx];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc[j] = mfma16(a, s_rows[bidx[j]], acc[j], T{});
+      __syncthreads();
+    }
+    // accumulators -> S[g][m][ry*WC + col] (col = 16*run + n, m = 4*kg + reg)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int blk = sub + WPG * j;
+      if (blk < gh * NRUN) {
+        const int ry = blk / NRUN, run = blk - ry * NRUN;
+        float* dst = s_S + (size_t)(gi * 16 + 4 * kg) * MS + ry * WC + 16 * run + n;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) dst[r4 * MS] = acc[j][r4] * p.scale;
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < TP * K; e += kThreads) {
+      int pix, k;
+      if (p.out_nhwc) { pix = e / K; k = e - pix * K; } else { k = e / TP; pix = e - k * TP; }
+      const int y = ty0 + pix / TW, x = tx0 + pix % TW;
+      if (y >= H || x >= W) continue;
+      const int g = (pix % TW) >> 2;
+      const int* gq = s_meta + 8 + 4 * g;
+      const float* Sp = s_S + (size_t)frow(pix) * MS;
+      const int iy = k / N1, ix = k - iy * N1;
+      const int yy = s_y0[pix] - R + iy, xx = s_x0[pix] - R + ix;
+      const float ax = s_ax[pix], ay = s_ay[pix];
+      auto D = [&](int jj, int ii) -> float {
+        const int ya = yy + jj, xa = xx + ii;
+        return (ya >= 0 && ya < H && xa >= 0 && xa < W) ? Sp[(ya - gq[1]) * WC + (xa - gq[0])] : 0.f;
+      };
+      const float d00 = D(0, 0), d01 = D(0, 1), d10 = D(1, 0), d11 = D(1, 1);
+      const float top = d00 + ax * (d01 - d00), bot = d10 + ax * (d11 - d10);
+      out[feat_off(p.out_nhwc, b, k, y, x, p.out_pitch, H, W)] = from_f32<T>(top + ay * (bot - top));
+    }
+    return;
+  }
+
+  // =========================== incoherent tile: per-pixel patches on the VALU (mode B) ===========================
+  int g16, idx;
+  {
+    const int l5 = lane & 31;
+    int hg;
+    if (l5 < 4) { hg = 0; idx = l5; }
+    else if (l5 < 12) { hg = 1; idx = l5 - 4; }
+    else if (l5 < 16) { hg = 0; idx = l5 - 8; }
+    else if (l5 < 20) { hg = 1; idx = l5 - 8; }
+    else if (l5 < 28) { hg = 0; idx = l5 - 12; }
+    else { hg = 1; idx = l5 - 16; }
+    g16 = wave * 4 + (lane >> 5) * 2 + hg;
+  }
+  constexpr int UB = (SB * NIT + 15) / 16;
+  for (int pass = 0; pass < (TP + SB - 1) / SB; ++pass) {
+    int pixw[UB], qw[UB], rowidx[UB];
+    float acc[UB];
+#pragma unroll
+    for (int w = 0; w < UB; ++w) {
+      const int u = g16 + 16 * w;
+      const int slot = u / NIT, it = u - slot * NIT;
+      int pix = (u < SB * NIT) ? pass * SB + slot : TP;
+      const bool pact = pix < TP;
+      pix = pact ? pix : 0;
+      const bool pvalid = pact && (ty0 + pix / TW < H) && (tx0 + pix % TW < W);
+      const int q = it * 16 + idx;
+      const int yy = s_y0[pix] - R + q / N2, xx = s_x0[pix] - R + q % N2;
+      const bool ok = pvalid && (q < Q) && (yy >= 0) && (yy < H) && (xx >= 0) && (xx < W);
+      pixw[w] = pvalid ? pix : -1;
+      qw[w] = q;
+      rowidx[w] = ok ? TP + slot * QP + q : ZROW;
+      acc[w] = 0.f;
+    }
+    const T* src[NL];
+    const int used_rows = TP + SB * QP;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      const int slot = l * kThreads + tid;
+      const int row = slot >> 2;
+      const int k = (slot & 3) ^ ((row >> 2) & 1);
+      int y = ty0, x = tx0, pitch = p.f0_pitch;
+      const T* base = f0;
+      if (row < TP) {
+        fpix(row, y, x);
+        y = min(y, H - 1);
+        x = min(x, W - 1);
+      } else if (row < used_rows) {
+        const int rr = row - TP;
+        const int sl = rr / QP, q = rr - sl * QP;
+        const int pix = pass * SB + sl;
+        if (pix < TP && q < Q) {
+          y = min(max(s_y0[pix] - R + q / N2, 0), H - 1);
+          x = min(max(s_x0[pix] - R + q % N2, 0), W - 1);
+          base = f1;
+          pitch = p.f1_pitch;
+        }
+      }
+      src[l] = base + ((size_t)y * W + x) * pitch + k * E16;
+    }
+    const int nl_used = (((used_rows + 15) & ~15) * PK + kThreads - 1) / kThreads;
+    for (int c0 = 0; c0 < p.C; c0 += CC) {
+#pragma unroll
+      for (int l = 0; l < NL; ++l)
+        if (l < nl_used) dma16(src[l] + c0, smem + (size_t)(l * kThreads + (tid & ~63)) * 16);
+      __syncthreads();
+#pragma unroll
+      for (int w = 0; w < UB; ++w) {
+        const int prow = frow(pixw[w] < 0 ? 0 : pixw[w]);
+        const int r0 = rowidx[w];
+        float sacc = acc[w];
+#pragma unroll
+        for (int k = 0; k < PK; ++k) sacc = dot16<T>(s_rows[swz1(prow, k)], s_rows[swz1(r0, k)], sacc);
+        acc[w] = sacc;
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int w = 0; w < UB; ++w)
+      if (qw[w] < Q && pixw[w] >= 0) s_D[pixw[w] * (Q + 1) + qw[w]] = acc[w] * p.scale;
+  }
+  __syncthreads();
+  for (int e = tid; e < TP * K; e += kThreads) {
+    int pix, k;
+    if (p.out_nhwc) { pix = e / K; k = e - pix * K; } else { k = e / TP; pix = e - k * TP; }
+    const int y = ty0 + pix / TW, x = tx0 + pix % TW;
+    if (y >= H || x >= W) continue;
+    const int iy = k / N1, ix = k - iy * N1;
+    const float ax = s_ax[pix], ay = s_ay[pix];
+    const float* d = s_D + pix * (Q + 1) + iy * N2 + ix;
+    const float top = d[0] + ax * (d[1] - d[0]);
+    const float bot = d[N2] + ax * (d[N2 + 1] - d[N2]);
+    out[feat_off(p.out_nhwc, b, k, y, x, p.out_pitch, H, W)] = from_f32<T>(top + ay * (bot - top));
+  }
+}
+
+template <typename T, int R>
+int launch_lc_mfma(LCParams p, hipStream_t stream) {
+  using M = LCM<R>;
+  constexpr int Q = (2 * R + 2) * (2 * R + 2);
+  constexpr int NL = ((M::TP + M::MAXR) * 4 + kThreads - 1) / kThreads;
+  constexpr int BODY16 = (NL * kThreads + 64) > (M::NG * 16 * M::MS / 4 + 1) ? (NL * kThreads + 64) : (M::NG * 16 * M::MS / 4 + 1);
+  p.tiles_x = (p.W + M::TW - 1) / M::TW;
+  p.tiles_y = (p.H + M::TH - 1) / M::TH;
+  p.max_rows = M::MAXR;
+  const size_t smem = (size_t)BODY16 * 16 + (size_t)M::TP * (Q + 1) * 4 + (8 + 4 * M::NG + 2 * M::TP) * 4 + 2 * M::TP * 4;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(local_corr_mfma_kernel<T, R>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) { set_error("roma_local_corr: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    attr_done = true;
+  }
+  const int grid = p.B * p.tiles_x * p.tiles_y;
+  hipLaunchKernelGGL((local_corr_mfma_kernel<T, R>), dim3(grid), dim3(kThreads), smem, stream, p);
+  ROMA_CHECK_LAUNCH();
+}
+
 template <typename T, int R>
 int launch_lc(LCParams p, hipStream_t stream) {
   using G = LCGeom<R>;
@@ -541,8 +870,13 @@ int launch_lc(LCParams p, hipStream_t stream) {
 
 template <typename T, int R>
 int launch_any(const LCParams& p, hipStream_t s) {
-  constexpr int CC = 4 * ElemTraits<T>::kPer16B;                // the fast path streams whole 64-byte channel chunks
-  return (p.in_nhwc && p.C % CC == 0) ? launch_lc_nhwc<T, R>(p, s) : launch_lc<T, R>(p, s);
+  constexpr int CC = 4 * ElemTraits<T>::kPer16B;                // the fast paths stream whole 64-byte channel chunks
+  if (!(p.in_nhwc && p.C % CC == 0)) return launch_lc<T, R>(p, s);
+  if constexpr (sizeof(T) == 2) {
+    return launch_lc_mfma<T, R>(p, s);
+  } else {
+    return launch_lc_nhwc<T, R>(p, s);
+  }
 }
 
 template <typename T>
