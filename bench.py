@@ -215,6 +215,7 @@ def main():
             a = lc["bytes"] / lc["seconds"]
             roof = {"bound": "hbm", "kernel": "local_corr_kernel", "achieved": a / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                     "frac": a / HBM_PEAK, "traffic": None, "launches": lc["launches"],
+                    "event_bracket_overhead_us": ops.TIMER.bracket_overhead_s * 1e6,
                     "avg_launch_us": lc["seconds"] / lc["launches"] * 1e6, "algorithmic_bytes_per_launch": lc["bytes"] / lc["launches"],
                     "per_shape": {k: {"us": v[2] / v[0] * 1e6, "GB/s": v[1] / v[2] / 1e9} for k, v in sorted(lc["by_tag"].items())}}
             pmc = os.path.join(ROOT, "profiles", "local_corr_traffic.json")

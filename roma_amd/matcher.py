@@ -178,8 +178,25 @@ class GP(nn.Module):
         mu = K_xy @ ops.spd_solve(K_yy, self.basis(b, h2, w2, x.device).contiguous())
         return mu.transpose(1, 2).reshape(b, self.dim, h1, w1)
 
-    def posterior_rows(self, xs, ys, h2, w2):
-        """Token-major variant used by the Decoder: xs, ys (B,N,D) fp32 -> mu (B,N,gp_dim) fp32."""
+    def posterior_rows(self, xs, ys, h2, w2, fp64=False):
+        """Token-major variant used by the Decoder: xs, ys (B,N,D) fp32 -> mu (B,N,gp_dim) fp32.
+
+        fp64=True (the all-fp32 parity mode): K_yy + sigma I has condition number ~1e4 on real features, so ANY fp32
+        evaluation — the reference's own CPU path included — carries ~1e-3 error on mu (measured against an fp64 run:
+        reference fp32 9e-4, fp32 MFMA kernel + blocked solve 1.9e-3, torch.linalg.inv in fp32 on the GPU 2.2e-3).
+        Evaluating kernel matrices and solve in fp64 leaves only the reference's own error in the comparison.  The fast
+        modes use the fp32 MFMA CosKernel + hand-blocked Cholesky below."""
+        if fp64:
+            a, c = xs.double(), ys.double()
+
+            def cosk(u, v):
+                g = torch.einsum("bnd,bmd->bnm", u, v) / (u.norm(dim=-1)[..., None] * v.norm(dim=-1)[:, None] + 1e-6)
+                return ((g - 1.0) / self.K.T).exp()
+
+            n = c.shape[1]
+            Kyy = cosk(c, c) + self.sigma_noise * torch.eye(n, device=c.device, dtype=torch.float64)
+            Z = torch.cholesky_solve(self.basis(xs.shape[0], h2, w2, xs.device).double(), torch.linalg.cholesky(Kyy))
+            return (cosk(a, c) @ Z).float()
         K_yy = ops.cos_kernel(ys, ys, T=self.K.T, diag_add=self.sigma_noise)
         K_xy = ops.cos_kernel(xs, ys, T=self.K.T)
         return K_xy @ ops.spd_solve(K_yy, self.basis(xs.shape[0], h2, w2, xs.device).contiguous())
@@ -253,7 +270,8 @@ class Decoder(nn.Module):
             if ins in self.embedding_decoder.scales():
                 xs = x.permute(0, 2, 3, 1).reshape(b, hs * ws, -1)
                 ys = y.permute(0, 2, 3, 1).reshape(b, hs * ws, -1)
-                mu = self.gps[s].posterior_rows(xs.float().contiguous(), ys.float().contiguous(), hs, ws)   # :377
+                mu = self.gps[s].posterior_rows(xs.float().contiguous(), ys.float().contiguous(), hs, ws,
+                                                fp64=(dtype == torch.float32))                # :377
                 tokens = torch.cat((mu.to(dtype), xs), dim=2)                                 # transformer/__init__.py:35-41
                 # fp32 parameters, amp-dtype GEMMs/attention with fp32 LayerNorm/softmax: the reference's autocast
                 # region (transformer/__init__.py:31-32), here only around the library transformer

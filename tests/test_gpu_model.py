@@ -44,6 +44,27 @@ def test_gp_golden():
         assert maxerr(mu, H.T(g[f"{name}_mu"])) < 2e-5
 
 
+def test_gp_fast_path_vs_fp64_on_real_features(full_model):
+    """The fp32 MFMA CosKernel + hand-blocked Cholesky (fast modes) against the fp64 evaluation (parity mode) on the
+    DINOv2 features of a real photograph: the system has condition number ~1e4, so fp32 agrees to a few 1e-3 only."""
+    from PIL import Image
+    from roma_amd.matcher import preprocess
+    _set_dtype(full_model, torch.float32)
+    ims = [Image.open(H.asset(f"sacre_coeur_{n}.jpg")).convert("RGB") for n in "AB"]
+    X = torch.cat([preprocess(im, (560, 560))[None] for im in ims]).to(DEV)
+    f16 = full_model.encoder(X)[16]
+    x = full_model.decoder.project("16", f16, torch.float32)
+    y = torch.cat((x[1:], x[:1]))
+    xs = x.permute(0, 2, 3, 1).reshape(2, 1600, -1).float().contiguous()
+    ys = y.permute(0, 2, 3, 1).reshape(2, 1600, -1).float().contiguous()
+    gp = full_model.decoder.gps["16"]
+    fast = gp.posterior_rows(xs, ys, 40, 40, fp64=False)
+    exact = gp.posterior_rows(xs, ys, 40, 40, fp64=True)
+    err = float((fast - exact).abs().max())
+    print(f"GP fast (fp32 MFMA + blocked Cholesky) vs fp64: max|d| = {err:.2e}, |mu| max = {float(exact.abs().max()):.2f}")
+    assert err < 1e-2
+
+
 def test_decoder_both_modes_golden():
     g = H.golden("decoder")
     dec = H.load_recipe_weights(H.build_reduced_decoder(_M()), "dec.", gains=cases.DEC_GAINS).to(DEV)
