@@ -156,12 +156,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no ROCm device is visible (there is no CPU fallback path)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    torch.cuda.set_device(local_rank % ndev)
+    device = torch.device("cuda", local_rank % ndev)
     import torch.distributed as dist
+    backend = os.environ.get("ROMA_BENCH_BACKEND", "nccl")        # "gloo" only for rehearsing N>1 on a one-GPU box
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
     if args.gpus != world and rank == 0:
         log(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}")
 
@@ -184,6 +189,8 @@ def main():
     def step():
         warp, cert = model.match_tensors(A_lo, B_lo, A_hi, B_hi)
         if world > 1:
+            if backend != "nccl":                       # rehearsal path: gloo gathers host tensors
+                warp, cert = warp.cpu(), cert.cpu()
             warp, cert = gather_results(warp, cert, world * P, dst=0)
         return warp, cert
 
@@ -204,7 +211,7 @@ def main():
     elapsed = time.perf_counter() - t0
     ops.TIMER.stop()
     if world > 1:
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

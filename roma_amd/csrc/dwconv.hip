@@ -6,90 +6,79 @@
 // XS output pixels along W, streams the (XS+4) input columns of each of the 5 rows through registers once and
 // reuses every loaded packet for up to 5 taps x XS outputs; fp32 accumulation.  Lanes run along the channel
 // packets, so a wavefront's loads are 1 KiB contiguous for C >= 512 (fp16).
+#include <cstdlib>
 #include "common.h"
 
 namespace roma {
 namespace {
 
-constexpr int XS = 4;
-
-template <typename T>
+// Register tile per thread: XS x YS output pixels of one 16-byte channel packet; the (XS+4) x (YS+4) input patch is
+// streamed row by row through registers, every loaded packet feeding up to 5 x min(5,YS-ish) x XS FMAs.
+template <typename T, int XS, int YS>
 __global__ __launch_bounds__(256) void dwconv5x5_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                                         T* __restrict__ y, int B, int C, int H, int W, int x_pitch, int y_pitch) {
   constexpr int E = ElemTraits<T>::kPer16B;
   const int PK = C / E;
-  const int WS = (W + XS - 1) / XS;
-  const size_t total = (size_t)B * H * WS * PK;
+  const int WS = (W + XS - 1) / XS, HS = (H + YS - 1) / YS;
+  const size_t total = (size_t)B * HS * WS * PK;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int k = (int)(i % PK);
     size_t r = i / PK;
     const int xs = (int)(r % WS) * XS; r /= WS;
-    const int yo = (int)(r % H);
-    const int b = (int)(r / H);
+    const int ys = (int)(r % HS) * YS;
+    const int b = (int)(r / HS);
     const int c0 = k * E;
-    float acc[XS][E];
+    float acc[YS][XS][E];
 #pragma unroll
-    for (int o = 0; o < XS; ++o)
+    for (int oy = 0; oy < YS; ++oy)
 #pragma unroll
-      for (int e = 0; e < E; ++e) acc[o][e] = 0.f;
+      for (int o = 0; o < XS; ++o)
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[oy][o][e] = 0.f;
     const T* xb = x + (size_t)b * H * W * x_pitch + c0;
-    // interior strips (all but a 2-pixel frame) run with unconditional loads; a guarded load makes hipcc branch and
-    // wait vmcnt(0) per element.  Border strips clamp the address and zero the tap through its weight.
-    const bool interior = yo >= 2 && yo + 2 < H && xs >= 2 && xs + XS + 2 <= W;
-    if (interior) {
+    // interior patches (all but a 2-pixel frame) run with unconditional loads; a guarded load makes hipcc branch and
+    // wait vmcnt(0) per element.  Border patches clamp the address and zero the tap through a mask.
+    const bool interior = ys >= 2 && ys + YS + 2 <= H && xs >= 2 && xs + XS + 2 <= W;
+#pragma unroll 1
+    for (int iy = 0; iy < YS + 4; ++iy) {                           // rolled: one input row in registers at a time
+      const int yi = ys + iy - 2;
+      const float my = (yi >= 0 && yi < H) ? 1.f : 0.f;
+      const T* row = xb + (size_t)min(max(yi, 0), H - 1) * W * x_pitch;
+      u32x4 raw[XS + 4];
+      if (interior) {
 #pragma unroll
-      for (int dy = 0; dy < 5; ++dy) {
+        for (int cx = 0; cx < XS + 4; ++cx) raw[cx] = *reinterpret_cast<const u32x4*>(row + (size_t)(xs - 2 + cx) * x_pitch);
+      } else {
+#pragma unroll
+        for (int cx = 0; cx < XS + 4; ++cx) raw[cx] = *reinterpret_cast<const u32x4*>(row + (size_t)min(max(xs - 2 + cx, 0), W - 1) * x_pitch);
+      }
+#pragma unroll
+      for (int oy = 0; oy < YS; ++oy) {
+        const int dy = iy - oy;                                   // tap row of output row oy fed by input row iy
+        if (dy < 0 || dy > 4) continue;
         float wr[5][E];
 #pragma unroll
         for (int dx = 0; dx < 5; ++dx)
 #pragma unroll
           for (int e = 0; e < E; e += 4)
             *reinterpret_cast<float4_t*>(&wr[dx][e]) = *reinterpret_cast<const float4_t*>(w + (size_t)(dy * 5 + dx) * C + c0 + e);
-        const T* row = xb + ((size_t)(yo + dy - 2) * W + (xs - 2)) * x_pitch;
-        u32x4 raw[XS + 4];
-#pragma unroll
-        for (int cx = 0; cx < XS + 4; ++cx) raw[cx] = *reinterpret_cast<const u32x4*>(row + (size_t)cx * x_pitch);
 #pragma unroll
         for (int cx = 0; cx < XS + 4; ++cx) {
           float f[E];
           unpack16<T>(raw[cx], f);
+          if (!interior) {
+            const int xi = xs - 2 + cx;
+            const float m = (xi >= 0 && xi < W) ? my : 0.f;
 #pragma unroll
-          for (int dx = 0; dx < 5; ++dx) {
-            const int o = cx - dx;
-            if (o >= 0 && o < XS) {
-#pragma unroll
-              for (int e = 0; e < E; ++e) acc[o][e] = __builtin_fmaf(wr[dx][e], f[e], acc[o][e]);
-            }
+            for (int e = 0; e < E; ++e) f[e] *= m;
           }
-        }
-      }
-    } else {
-#pragma unroll 1
-      for (int dy = 0; dy < 5; ++dy) {
-        const int yi = yo + dy - 2;
-        const float my = (yi >= 0 && yi < H) ? 1.f : 0.f;
-        const int yc = min(max(yi, 0), H - 1);
-        float wr[5][E];
-#pragma unroll
-        for (int dx = 0; dx < 5; ++dx)
-#pragma unroll
-          for (int e = 0; e < E; e += 4)
-            *reinterpret_cast<float4_t*>(&wr[dx][e]) = *reinterpret_cast<const float4_t*>(w + (size_t)(dy * 5 + dx) * C + c0 + e);
-        const T* row = xb + (size_t)yc * W * x_pitch;
-#pragma unroll
-        for (int cx = 0; cx < XS + 4; ++cx) {
-          const int xi = xs + cx - 2;
-          const float m = (xi >= 0 && xi < W) ? my : 0.f;
-          const int xc = min(max(xi, 0), W - 1);
-          float f[E];
-          unpack16<T>(*reinterpret_cast<const u32x4*>(row + (size_t)xc * x_pitch), f);
 #pragma unroll
           for (int dx = 0; dx < 5; ++dx) {
             const int o = cx - dx;
             if (o >= 0 && o < XS) {
 #pragma unroll
-              for (int e = 0; e < E; ++e) acc[o][e] = __builtin_fmaf(wr[dx][e] * m, f[e], acc[o][e]);
+              for (int e = 0; e < E; ++e) acc[oy][o][e] = __builtin_fmaf(wr[dx][e], f[e], acc[oy][o][e]);
             }
           }
         }
@@ -101,16 +90,30 @@ __global__ __launch_bounds__(256) void dwconv5x5_kernel(const T* __restrict__ x,
       *reinterpret_cast<float4_t*>(&sc[e]) = *reinterpret_cast<const float4_t*>(scale + c0 + e);
       *reinterpret_cast<float4_t*>(&sh[e]) = *reinterpret_cast<const float4_t*>(shift + c0 + e);
     }
-    T* yrow = y + (((size_t)b * H + yo) * W) * y_pitch + c0;
 #pragma unroll
-    for (int o = 0; o < XS; ++o) {
-      if (xs + o >= W) break;
-      float v[E];
+    for (int oy = 0; oy < YS; ++oy) {
+      if (ys + oy >= H) break;
+      T* yrow = y + (((size_t)b * H + ys + oy) * W) * y_pitch + c0;
 #pragma unroll
-      for (int e = 0; e < E; ++e) v[e] = fmaxf(__builtin_fmaf(acc[o][e], sc[e], sh[e]), 0.f);
-      *reinterpret_cast<u32x4*>(yrow + (size_t)(xs + o) * y_pitch) = pack16<T>(v);
+      for (int o = 0; o < XS; ++o) {
+        if (xs + o >= W) break;
+        float v[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = fmaxf(__builtin_fmaf(acc[oy][o][e], sc[e], sh[e]), 0.f);
+        *reinterpret_cast<u32x4*>(yrow + (size_t)(xs + o) * y_pitch) = pack16<T>(v);
+      }
     }
   }
+}
+
+template <typename T, int XS, int YS>
+void launch_dw(const void* x, const float* w, const float* scale, const float* shift, void* y, int B, int C, int H, int W,
+               int x_pitch, int y_pitch, hipStream_t s) {
+  constexpr int E = ElemTraits<T>::kPer16B;
+  const size_t total = (size_t)B * ((H + YS - 1) / YS) * ((W + XS - 1) / XS) * (C / E);
+  size_t g = (total + 255) / 256;
+  if (g > 32768) g = 32768;
+  hipLaunchKernelGGL((dwconv5x5_kernel<T, XS, YS>), dim3((int)g), dim3(256), 0, s, (const T*)x, w, scale, shift, (T*)y, B, C, H, W, x_pitch, y_pitch);
 }
 
 }  // namespace
@@ -127,15 +130,22 @@ extern "C" int roma_dwconv5x5_bn_relu(const void* x, const float* w, const float
   ROMA_REQUIRE(C % e == 0 && x_pitch % e == 0 && y_pitch % e == 0 && aligned16(x) && aligned16(y) && aligned16(w) &&
                    aligned16(scale) && aligned16(shift),
                ROMA_E_ALIGN, "roma_dwconv5x5_bn_relu: C and pitches must be multiples of %d, all bases 16-byte aligned", e);
-  const size_t total = (size_t)B * H * ((W + XS - 1) / XS) * (C / e);
-  size_t g = (total + 255) / 256;
-  if (g > 16384) g = 16384;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (dtype == ROMA_F32)
-    hipLaunchKernelGGL((dwconv5x5_kernel<float>), dim3((int)g), dim3(256), 0, s, (const float*)x, w, scale, shift, (float*)y, B, C, H, W, x_pitch, y_pitch);
-  else if (dtype == ROMA_F16)
-    hipLaunchKernelGGL((dwconv5x5_kernel<half_t>), dim3((int)g), dim3(256), 0, s, (const half_t*)x, w, scale, shift, (half_t*)y, B, C, H, W, x_pitch, y_pitch);
-  else
-    hipLaunchKernelGGL((dwconv5x5_kernel<bf16_t>), dim3((int)g), dim3(256), 0, s, (const bf16_t*)x, w, scale, shift, (bf16_t*)y, B, C, H, W, x_pitch, y_pitch);
+  // tile shape: ROMA_DW_TILE=XSxYS overrides (tuning aid); default 8x1
+  static int tile = -1;
+  if (tile < 0) {
+    const char* ev = getenv("ROMA_DW_TILE");
+    tile = ev ? atoi(ev) : 81;
+  }
+#define ROMA_DW(T)                                                                                                    \
+  switch (tile) {                                                                                                     \
+    case 41: launch_dw<T, 4, 1>(x, w, scale, shift, y, B, C, H, W, x_pitch, y_pitch, s); break;                       \
+    case 42: launch_dw<T, 4, 2>(x, w, scale, shift, y, B, C, H, W, x_pitch, y_pitch, s); break;                       \
+    case 82: launch_dw<T, 8, 2>(x, w, scale, shift, y, B, C, H, W, x_pitch, y_pitch, s); break;                       \
+    case 44: launch_dw<T, 4, 4>(x, w, scale, shift, y, B, C, H, W, x_pitch, y_pitch, s); break;                       \
+    default: launch_dw<T, 8, 1>(x, w, scale, shift, y, B, C, H, W, x_pitch, y_pitch, s); break;                       \
+  }
+  if (dtype == ROMA_F32) { ROMA_DW(float) } else if (dtype == ROMA_F16) { ROMA_DW(half_t) } else { ROMA_DW(bf16_t) }
+#undef ROMA_DW
   ROMA_CHECK_LAUNCH();
 }
