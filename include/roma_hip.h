@@ -108,6 +108,12 @@ int roma_kde_density(const float* x, float* density, int N, int down, float std,
 int roma_dwconv5x5_bn_relu(const void* x, const float* w, const float* scale, const float* shift, void* y,
                            int B, int C, int H, int W, int dtype, int x_pitch, int y_pitch, void* stream);
 
+/* ConvRefiner block back half for NARROW activations — matcher.py:102 (Conv2d(D, D, 1) of create_block) at D <= 32:
+ *   y[m][n] = bias[n] + sum_k x[m][k] * wt[k][n],  x,y: (M, pitch) channels-last rows of `dtype`, wt (C,C) fp32 row-major
+ *   (in, out), bias (C) fp32.  C a multiple of 8 (fp16/bf16) or 4 (fp32), C <= 32. */
+int roma_pointwise_small(const void* x, const float* wt, const float* bias, void* y, long M, int C, int dtype,
+                         int x_pitch, int y_pitch, void* stream);
+
 /* TinyRoMa corr_volume + pos_embed fused — tiny.py:241-254, 178-203: for every source pixel the soft-argmax target
  * coordinate over the full correlation row, without materialising the (H1W1 x H0W0) volume.
  *   f0: (B,H0*W0,C), f1: (B,H1*W1,C) row-major fp32 (C a multiple of 16); out (B,2,H0,W0) fp32.

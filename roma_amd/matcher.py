@@ -90,7 +90,11 @@ class ConvRefiner(nn.Module):
             wt[:D, :D] = pw.weight.float().reshape(D, D).t()            # (in, out): X @ wt
             b = torch.zeros(Dp, device=dev)
             b[:D] = pw.bias.float()
-            blocks.append((w25.contiguous(), scale, shift, wt.to(dtype).contiguous(), b.to(dtype)))
+            # narrow refiners (Dp <= 32): the 1x1 conv is a streaming op -> own kernel with fp32 weights; else a library GEMM
+            if Dp <= 32:
+                blocks.append((w25.contiguous(), scale, shift, wt.contiguous(), b.contiguous()))
+            else:
+                blocks.append((w25.contiguous(), scale, shift, wt.to(dtype).contiguous(), b.to(dtype)))
         wo = torch.zeros(Dp, self.out_dim, device=dev)
         wo[:D] = self.out_conv.weight.float().reshape(self.out_dim, D).t()
         prep = dict(D=D, Dp=Dp, blocks=blocks, wo=wo.contiguous(), bo=self.out_conv.bias.float(),
@@ -125,7 +129,8 @@ class ConvRefiner(nn.Module):
         cur = buf
         for (w25, scale, shift, wt, b) in P["blocks"]:                                         # :139-140
             t = ops.dwconv5x5_bn_relu(cur.permute(0, 3, 1, 2), w25, scale, shift)
-            cur = torch.addmm(b, t.permute(0, 2, 3, 1).reshape(M, Dp), wt).view(B, h, w, Dp)
+            rows = t.permute(0, 2, 3, 1).reshape(M, Dp)
+            cur = (ops.pointwise_small(rows, wt, b) if Dp <= 32 else torch.addmm(b, rows, wt)).view(B, h, w, Dp)
         out = torch.addmm(P["bo"], cur.reshape(M, Dp).float(), P["wo"])                        # out_conv in fp32, :141
         out = out.view(B, h, w, self.out_dim).permute(0, 3, 1, 2).contiguous()
         return out[:, :-1], out[:, -1:]
@@ -333,7 +338,7 @@ class RegressionMatcher(nn.Module):
         return self.encoder(batch["im_A"], upsample=upsample), self.encoder(batch["im_B"], upsample=upsample)
 
     def forward(self, batch, batched=True, upsample=False, scale_factor=1):
-        pyr = self.extract_backbone_features(batch, batched=batched, upsample=upsample)
+        pyr = batch.get("pyramid") or self.extract_backbone_features(batch, batched=batched, upsample=upsample)
         if batched:
             f_q = {s: f.chunk(2)[0] for s, f in pyr.items()}
             f_s = {s: f.chunk(2)[1] for s, f in pyr.items()}
@@ -342,7 +347,7 @@ class RegressionMatcher(nn.Module):
         return self.decoder(f_q, f_s, upsample=upsample, scale_factor=scale_factor, **(batch.get("corresps") or {}))
 
     def forward_symmetric(self, batch, batched=True, upsample=False, scale_factor=1):
-        pyr = self.extract_backbone_features(batch, batched=batched, upsample=upsample)       # matcher.py:516-528
+        pyr = batch.get("pyramid") or self.extract_backbone_features(batch, batched=batched, upsample=upsample)   # matcher.py:516-528
         kw = {k: v for k, v in (batch.get("corresps") or {}).items() if k in ("flow", "certainty")}
         return self.decoder(pyr, None, upsample=upsample, scale_factor=scale_factor, swapped_pair=True, **kw)
 
@@ -404,7 +409,18 @@ class RegressionMatcher(nn.Module):
         pass.  Returns the stack of per-pair results: warp (P,H,2W,4), certainty (P,H,2W) (symmetric) — the batched
         560->864 semantics the reference leaves undefined (its batched+upsample path raises)."""
         symmetric = self.symmetric
+        # The 864 VGG pyramid does not depend on the coarse pass: once the coarse encoders are queued, run it on a second
+        # HIP stream so that its large convolutions fill the CUs the coarse decoder's small, latency-bound kernels (GP
+        # solve, 40x40 / 70x70 refiners) leave idle.  Joined before the upsample decoder.
         batch = {"im_A": A_lo, "im_B": B_lo}
+        batch["pyramid"] = self.extract_backbone_features(batch, batched=True)
+        hi_pyr = None
+        if self.upsample_preds and A_hi is not None and B_hi is not None and getattr(self, "overlap_upsample_encoder", True):
+            main = torch.cuda.current_stream()
+            side = self._side_stream = getattr(self, "_side_stream", None) or torch.cuda.Stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                hi_pyr = self.extract_backbone_features({"im_A": A_hi, "im_B": B_hi}, batched=True, upsample=True)
         corresps = self.forward_symmetric(batch) if symmetric else self.forward(batch, batched=True)
         hs, ws = A_lo.shape[-2:]
         cert16 = corresps[16]["certainty"] if self.attenuate_cert else None
@@ -414,6 +430,9 @@ class RegressionMatcher(nn.Module):
             hs, ws = A_hi.shape[-2:]
             scale_factor = math.sqrt(hs * ws / (A_lo.shape[-2] * A_lo.shape[-1]))            # matcher.py:677
             batch = {"im_A": A_hi, "im_B": B_hi, "corresps": corresps[1]}
+            if hi_pyr is not None:
+                torch.cuda.current_stream().wait_stream(self._side_stream)
+                batch["pyramid"] = hi_pyr
             corresps = (self.forward_symmetric(batch, upsample=True, scale_factor=scale_factor) if symmetric
                         else self.forward(batch, batched=True, upsample=True, scale_factor=scale_factor))
         return ops.match_finalize(corresps[1]["flow"], corresps[1]["certainty"], cert16, symmetric=symmetric)

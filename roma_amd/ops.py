@@ -336,6 +336,19 @@ def dwconv5x5_bn_relu(x, w25, scale, shift, out=None):
     return out
 
 
+def pointwise_small(x_rows, wt, bias, out=None):
+    """1x1 convolution on narrow channels-last rows: x_rows (M, C) view with row stride >= C, wt (C, C) fp32 (in, out),
+    bias (C) fp32 — matcher.py:102 for the D = 24 refiner.  Returns (M, C) rows of x's dtype."""
+    _need_gpu(x_rows, wt, bias, out)
+    M, C = x_rows.shape
+    assert x_rows.stride(1) == 1
+    if out is None:
+        out = torch.empty((M, C), dtype=x_rows.dtype, device=x_rows.device)
+    check(_lib.load().roma_pointwise_small(_p(x_rows), _p(wt), _p(bias), _p(out), M, C, _dt(x_rows), x_rows.stride(0), out.stride(0),
+                                           _stream()), "roma_pointwise_small")
+    return out
+
+
 def tiny_corr_posembed(f0, f1, exact=False):
     """TinyRoMa.corr_volume + pos_embed fused — tiny.py:241-254,178-203.  f0 (B,C,H0,W0), f1 (B,C,H1,W1) -> (B,2,H0,W0)."""
     _need_gpu(f0, f1)

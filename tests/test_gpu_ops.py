@@ -270,6 +270,23 @@ def test_dwconv5x5_bn_relu(dtype, C, h, w):
     assert maxerr(out, ref) <= (2e-5 if dtype == torch.float32 else 4e-3)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("C", [8, 24, 32])
+def test_pointwise_small(dtype, C):
+    M = 5003
+    x = H.T(R.normal(f"pw.x.{C}", (M, C))).to(dtype)
+    wt = H.T(R.normal(f"pw.w.{C}", (C, C), scale=0.3))
+    b = H.T(R.normal(f"pw.b.{C}", (C,)))
+    ref = x.float() @ wt + b
+    out = _ops().pointwise_small(x.to(DEV), wt.to(DEV), b.to(DEV))
+    tol = {torch.float32: 1e-5, torch.float16: 4e-3, torch.bfloat16: 3e-2}[dtype]
+    assert out.dtype == dtype and maxerr(out, ref) <= tol * max(1.0, float(ref.abs().max()))
+    # strided rows (a channel slice of a wider channels-last buffer)
+    wide = torch.zeros(M, C + 16, dtype=dtype, device=DEV)
+    wide[:, :C] = x.to(DEV)
+    assert maxerr(_ops().pointwise_small(wide[:, :C], wt.to(DEV), b.to(DEV)), ref) <= tol * max(1.0, float(ref.abs().max()))
+
+
 # ---- TinyRoMa fused corr + pos_embed -----------------------------------------------------------
 def test_tiny_corr_posembed_golden():
     g = H.golden("tiny")
