@@ -108,6 +108,14 @@ int roma_kde_density(const float* x, float* density, int N, int down, float std,
 int roma_dwconv5x5_bn_relu(const void* x, const float* w, const float* scale, const float* shift, void* y,
                            int B, int C, int H, int W, int dtype, int x_pitch, int y_pitch, void* stream);
 
+/* ConvRefiner head + Decoder update fused — matcher.py:141 (out_conv, D -> 3, fp32 on d.float()) and :397-402:
+ *   d = bo + x[m,:] @ wo;  flow[b,0] += sx*d0;  flow[b,1] += sy*d1;  cert_out = (cert_in ? cert_in : 0) + d2
+ *   x: (B*H*W, pitch) channels-last rows of `dtype` (C channels used), wo (C,3) fp32 row-major, bo (3) fp32,
+ *   flow (B,2,H,W) fp32 updated in place, cert_in (B,1,H,W) or NULL, cert_out (B,1,H,W), delta_out (B,3,H,W) or NULL
+ *   (the raw out_conv result, for callers that want the reference's (displacement, certainty) return values). */
+int roma_refiner_head(const void* x, const float* wo, const float* bo, float* flow, const float* cert_in, float* cert_out,
+                      float* delta_out, int B, int H, int W, int C, int pitch, int dtype, float sx, float sy, void* stream);
+
 /* ConvRefiner block back half for NARROW activations — matcher.py:102 (Conv2d(D, D, 1) of create_block) at D <= 32:
  *   y[m][n] = bias[n] + sum_k x[m][k] * wt[k][n],  x,y: (M, pitch) channels-last rows of `dtype`, wt (C,C) fp32 row-major
  *   (in, out), bias (C) fp32.  C a multiple of 8 (fp16/bf16) or 4 (fp32), C <= 32. */

@@ -11,54 +11,61 @@ namespace {
 
 constexpr int NBMAX = 64;
 
-// A: lower triangle of the nb x nb block is read, L is written back to the lower triangle (upper untouched).
-// W: (nb x nb) row-major, receives L^-1 (lower triangular, zeros above the diagonal).
-// 256 threads: thread (r = tid & 63, part = tid >> 6) owns row r and a quarter of the columns / of the dot products.
-__global__ __launch_bounds__(256) void chol_diag_kernel(float* __restrict__ A, int lda, long strideA, float* __restrict__ W, int ldw,
-                                                        long strideW, int nb, int* __restrict__ info) {
-  constexpr int LD = NBMAX + 1;
-  __shared__ float L[NBMAX * LD], V[NBMAX * LD], Pp[4][NBMAX];
-  const int tid = threadIdx.x, b = blockIdx.x, r = tid & 63, part = tid >> 6;
+// One 64-lane wavefront per matrix, everything in registers: lane r owns ROW r of the (padded) 64 x 64 block.
+//  1. Cholesky, right-looking, column by column: the pivot row's entries are broadcast with v_readlane (static lane
+//     index, fully unrolled), so there is no LDS traffic and no barrier at all in the factorisation.
+//  2. L is written to LDS once; V = L^-1 by forward substitution with lane j owning COLUMN j of V (the columns are
+//     independent): v_i = (delta_ij - sum_{c<i} L[i][c] v_c) / L[i][i], L[i][c] being a wave-uniform broadcast read.
+// The previous 256-thread LDS version spent 83 us in ~260 barriers; this one is a straight-line wave program.
+__device__ __forceinline__ float lane_bcast(float v, int src_lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src_lane));
+}
+
+__global__ __launch_bounds__(64) void chol_diag_kernel(float* __restrict__ A, int lda, long strideA, float* __restrict__ W, int ldw,
+                                                       long strideW, int nb, int* __restrict__ info) {
+  __shared__ float Ls[NBMAX * NBMAX];
+  const int r = threadIdx.x, b = blockIdx.x;
   float* Ab = A + (size_t)b * strideA;
   float* Wb = W + (size_t)b * strideW;
-  for (int c = part; c < NBMAX; c += 4) {
-    L[r * LD + c] = (r < nb && c <= r) ? Ab[(size_t)r * lda + c] : (r == c ? 1.f : 0.f);   // identity padding beyond nb
-    V[r * LD + c] = 0.f;
-  }
-  __syncthreads();
-  // right-looking Cholesky, one column per step; row r updates its columns c = part, part+4, ...
-  for (int k = 0; k < nb; ++k) {
-    const float akk = L[k * LD + k];
-    if (tid == 0 && !(akk > 0.f)) info[b] = k + 1;
+  float a[NBMAX];                                   // row r of the block (lower part), identity-padded beyond nb
+#pragma unroll
+  for (int c = 0; c < NBMAX; ++c) a[c] = (r < nb && c < nb && c <= r) ? Ab[(size_t)r * lda + c] : (r == c ? 1.f : 0.f);
+  int bad = 0;
+#pragma unroll
+  for (int k = 0; k < NBMAX; ++k) {
+    const float akk = lane_bcast(a[k], k);
+    if (!(akk > 0.f) && bad == 0) bad = k + 1;
     const float inv = 1.f / sqrtf(fmaxf(akk, 1e-30f));
-    __syncthreads();
-    if (part == 0 && r >= k) L[r * LD + k] = (r == k) ? akk * inv : L[r * LD + k] * inv;
-    __syncthreads();
-    if (r > k) {
-      const float lrk = L[r * LD + k];
-      for (int c = k + 1 + part; c <= r; c += 4) L[r * LD + c] -= lrk * L[c * LD + k];
+    a[k] = (r >= k) ? a[k] * inv : a[k];            // column k scaled (row k: akk * inv = sqrt(akk))
+    const float lrk = a[k];
+#pragma unroll
+    for (int c = k + 1; c < NBMAX; ++c) {
+      const float lck = lane_bcast(a[k], c);        // L[c][k]
+      a[c] = (r >= c) ? a[c] - lrk * lck : a[c];
     }
   }
+  if (r == 0 && bad != 0 && bad <= nb) info[b] = bad;
+#pragma unroll
+  for (int c = 0; c < NBMAX; ++c) Ls[r * NBMAX + c] = a[c];
   __syncthreads();
-  // V = L^-1, one row per step: V[i][j] = (delta_ij - sum_{c=j}^{i-1} L[i][c] V[c][j]) / L[i][i], thread (j = r, part)
-  for (int i = 0; i < nb; ++i) {
-    const int j = r;
-    float sp = 0.f;
-    if (j < i)
-      for (int c = j + part; c < i; c += 4) sp += L[i * LD + c] * V[c * LD + j];
-    Pp[part][j] = sp;
-    __syncthreads();
-    if (part == 0 && j <= i) {
-      const float ssum = (Pp[0][j] + Pp[1][j]) + (Pp[2][j] + Pp[3][j]);
-      V[i * LD + j] = ((j == i ? 1.f : 0.f) - ssum) / L[i * LD + i];
-    }
-    __syncthreads();
+  // V = L^-1: lane j = column j
+  float v[NBMAX];
+#pragma unroll
+  for (int i = 0; i < NBMAX; ++i) {
+    float sacc = (i == r) ? 1.f : 0.f;
+#pragma unroll
+    for (int c = 0; c < i; ++c) sacc = __builtin_fmaf(-Ls[i * NBMAX + c], v[c], sacc);   // v[c] == 0 for c < j
+    v[i] = (i >= r) ? sacc / Ls[i * NBMAX + i] : 0.f;
   }
-  if (r < nb)
-    for (int c = part; c < nb; c += 4) {
-      if (c <= r) Ab[(size_t)r * lda + c] = L[r * LD + c];
-      Wb[(size_t)r * ldw + c] = (c <= r) ? V[r * LD + c] : 0.f;
-    }
+  if (r < nb) {
+#pragma unroll
+    for (int c = 0; c < NBMAX; ++c)
+      if (c < nb && c <= r) Ab[(size_t)r * lda + c] = a[c];
+  }
+  // lane j holds column j of V: W[i][j] = v[i]
+#pragma unroll
+  for (int i = 0; i < NBMAX; ++i)
+    if (i < nb && r < nb) Wb[(size_t)i * ldw + r] = v[i];
 }
 
 }  // namespace
@@ -70,6 +77,6 @@ extern "C" int roma_chol_diag_block(float* A, int lda, long strideA, float* W, i
                                     void* stream) {
   ROMA_REQUIRE(A && W && info, ROMA_E_ARG, "roma_chol_diag_block: null pointer");
   ROMA_REQUIRE(nb >= 1 && nb <= NBMAX && B >= 1 && lda >= nb && ldw >= nb, ROMA_E_SHAPE, "roma_chol_diag_block: bad shape nb=%d B=%d", nb, B);
-  hipLaunchKernelGGL(chol_diag_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), A, lda, strideA, W, ldw, strideW, nb, info);
+  hipLaunchKernelGGL(chol_diag_kernel, dim3(B), dim3(64), 0, static_cast<hipStream_t>(stream), A, lda, strideA, W, ldw, strideW, nb, info);
   ROMA_CHECK_LAUNCH();
 }

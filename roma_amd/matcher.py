@@ -103,10 +103,8 @@ class ConvRefiner(nn.Module):
         return prep
 
     @torch.no_grad()
-    def forward(self, x, y, flow, scale_factor=1, logits=None, dtype=None):
-        """x, y: (B,C,h,w) features; flow (B,2,h,w) fp32.  Returns (delta_flow (B,2,h,w), delta_certainty (B,1,h,w)) fp32
-        — matcher.py:105-143."""
-        dtype = dtype or self.amp_dtype
+    def _body(self, x, y, flow, scale_factor, dtype):
+        """Everything up to (not including) out_conv: returns the last block's activation (B,h,w,Dp) and the prepared weights."""
         P = self.prepare(dtype)
         B, C, h, w = x.shape
         D, Dp = P["D"], P["Dp"]
@@ -114,7 +112,6 @@ class ConvRefiner(nn.Module):
         r = self.local_corr_radius
         K = (2 * r + 1) ** 2 if r else 0
         assert 2 * C + E + K == D, "feature width does not match this refiner"
-        flow = flow.float().contiguous()
         buf = torch.empty((B, h, w, Dp), dtype=dtype, device=x.device)
         d = buf.permute(0, 3, 1, 2)
         d[:, :C].copy_(x)
@@ -131,9 +128,25 @@ class ConvRefiner(nn.Module):
             t = ops.dwconv5x5_bn_relu(cur.permute(0, 3, 1, 2), w25, scale, shift)
             rows = t.permute(0, 2, 3, 1).reshape(M, Dp)
             cur = (ops.pointwise_small(rows, wt, b) if Dp <= 32 else torch.addmm(b, rows, wt)).view(B, h, w, Dp)
-        out = torch.addmm(P["bo"], cur.reshape(M, Dp).float(), P["wo"])                        # out_conv in fp32, :141
+        return cur, P
+
+    @torch.no_grad()
+    def forward(self, x, y, flow, scale_factor=1, logits=None, dtype=None):
+        """x, y: (B,C,h,w) features; flow (B,2,h,w) fp32.  Returns (delta_flow (B,2,h,w), delta_certainty (B,1,h,w)) fp32
+        — matcher.py:105-143."""
+        flow = flow.float().contiguous()
+        cur, P = self._body(x, y, flow, scale_factor, dtype or self.amp_dtype)
+        B, h, w, Dp = cur.shape
+        out = torch.addmm(P["bo"], cur.reshape(B * h * w, Dp).float(), P["wo"])                # out_conv in fp32, :141
         out = out.view(B, h, w, self.out_dim).permute(0, 3, 1, 2).contiguous()
         return out[:, :-1], out[:, -1:]
+
+    @torch.no_grad()
+    def forward_update(self, x, y, flow, certainty, scale_factor, sx, sy, dtype=None):
+        """The Decoder's use of the refiner (matcher.py:393-402) with out_conv fused into the update kernel:
+        flow (B,2,h,w) fp32 contiguous is updated IN PLACE by (sx*dx, sy*dy); returns (flow, certainty + dcert)."""
+        cur, P = self._body(x, y, flow, scale_factor, dtype or self.amp_dtype)
+        return ops.refiner_head(cur, P["wo"], P["bo"], flow, certainty, sx, sy)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -283,9 +296,8 @@ class Decoder(nn.Module):
                 with torch.autocast("cuda", enabled=dtype != torch.float32, dtype=dtype if dtype != torch.float32 else None):
                     rows = self.embedding_decoder.forward_rows(tokens)                        # (b, hw, 4097)
                 flow, certainty = ops.cls_rows_to_flow(rows, b, hs, ws)                       # :378-385
-            delta, dcert = self.conv_refiner[s](x, y, flow, scale_factor=scale_factor, logits=certainty, dtype=dtype)   # :393
-            flow = flow + ins * torch.stack((delta[:, 0] / (self.refine_init * w), delta[:, 1] / (self.refine_init * h)), dim=1)
-            certainty = dcert if certainty is None else certainty + dcert                     # :397-402
+            flow, certainty = self.conv_refiner[s].forward_update(                             # :393-402
+                x, y, flow, certainty, scale_factor, ins / (self.refine_init * w), ins / (self.refine_init * h), dtype=dtype)
             corresps[ins].update({"certainty": certainty, "flow": flow})
             if s != "1":
                 flow = ops.interp_bilinear(flow, sizes[ins // 2])                             # :408-417

@@ -336,6 +336,22 @@ def dwconv5x5_bn_relu(x, w25, scale, shift, out=None):
     return out
 
 
+def refiner_head(x_nhwc, wo, bo, flow, certainty, sx, sy, want_delta=False):
+    """out_conv (D -> 3, fp32) of the last refiner block fused with the flow / certainty update (matcher.py:141, 397-402).
+    x_nhwc: (B,h,w,pitch) channels-last activation; wo (C,3) fp32; bo (3) fp32; flow (B,2,h,w) fp32 is updated IN PLACE;
+    certainty (B,1,h,w) fp32 or None.  Returns (flow, new_certainty[, delta (B,3,h,w)])."""
+    _need_gpu(x_nhwc, wo, bo, flow, certainty)
+    B, h, w, pitch = x_nhwc.shape
+    C = wo.shape[0]
+    assert x_nhwc.is_contiguous() and flow.is_contiguous() and flow.dtype == torch.float32 and wo.is_contiguous()
+    cert_in = None if certainty is None else certainty.float().contiguous()
+    cert = torch.empty((B, 1, h, w), dtype=torch.float32, device=flow.device)
+    delta = torch.empty((B, 3, h, w), dtype=torch.float32, device=flow.device) if want_delta else None
+    check(_lib.load().roma_refiner_head(_p(x_nhwc), _p(wo), _p(bo), _p(flow), _p(cert_in), _p(cert), _p(delta), B, h, w, C, pitch,
+                                        _dt(x_nhwc), float(sx), float(sy), _stream()), "roma_refiner_head")
+    return (flow, cert, delta) if want_delta else (flow, cert)
+
+
 def pointwise_small(x_rows, wt, bias, out=None):
     """1x1 convolution on narrow channels-last rows: x_rows (M, C) view with row stride >= C, wt (C, C) fp32 (in, out),
     bias (C) fp32 — matcher.py:102 for the D = 24 refiner.  Returns (M, C) rows of x's dtype."""

@@ -287,6 +287,27 @@ def test_pointwise_small(dtype, C):
     assert maxerr(_ops().pointwise_small(wide[:, :C], wt.to(DEV), b.to(DEV)), ref) <= tol * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("C,pitch", [(24, 24), (144, 144), (569, 576), (1377, 1384)])
+def test_refiner_head(dtype, C, pitch):
+    B, h, w = 2, 9, 11
+    x = torch.zeros(B, h, w, pitch)
+    x[..., :C] = H.T(R.normal(f"rh.x.{C}", (B, h, w, C)))
+    x = x.to(dtype)
+    wo = torch.zeros(pitch, 3)
+    wo[:C] = H.T(R.normal(f"rh.w.{C}", (C, 3), scale=1.0 / math.sqrt(C)))
+    bo = H.T(R.normal("rh.b", (3,)))
+    flow = H.T(R.coherent_flow("rh.flow", B, h, w))
+    cert = H.T(R.normal("rh.cert", (B, 1, h, w)))
+    d = (x.float().reshape(-1, pitch) @ wo + bo).reshape(B, h, w, 3).permute(0, 3, 1, 2)
+    ref_flow = flow + torch.stack((0.01 * d[:, 0], 0.02 * d[:, 1]), 1)
+    f2, c2, delta = _ops().refiner_head(x.to(DEV), wo.to(DEV), bo.to(DEV), flow.clone().to(DEV), cert.to(DEV), 0.01, 0.02, want_delta=True)
+    tol = 1e-5 if dtype == torch.float32 else 1e-4
+    assert maxerr(delta, d) < tol * 10 and maxerr(f2, ref_flow) < tol and maxerr(c2, cert + d[:, 2:]) < tol * 10
+    f3, c3 = _ops().refiner_head(x.to(DEV), wo.to(DEV), bo.to(DEV), flow.clone().to(DEV), None, 0.01, 0.02)
+    assert maxerr(c3, d[:, 2:]) < tol * 10
+
+
 # ---- TinyRoMa fused corr + pos_embed -----------------------------------------------------------
 def test_tiny_corr_posembed_golden():
     g = H.golden("tiny")
