@@ -74,6 +74,33 @@ def main():
     rows = torch.randn(B, 1600, 4097, device="cuda").to(dt)
     t = timeit(lambda: ops.cls_rows_to_flow(rows, B, 40, 40), iters=20)
     print(f"cls_rows_to_flow: {t*1e6:.1f} us  {rows.numel()*es/t/1e9:.1f} GB/s")
+    # warp (grid_sample) at the refiner shapes, finalize, narrow pointwise, fused head, tiny corr+soft-argmax
+    for C, h in [(512, 40), (512, 70), (256, 140), (64, 280), (512, 108), (256, 216), (64, 432)]:
+        y = torch.randn(B, C, h, h, device="cuda").to(dt).contiguous(memory_format=torch.channels_last)
+        flow = torch.from_numpy(R.coherent_flow("bench", B, h, h)).cuda()
+        o = ops.nhwc_empty(B, C, h, h, dt, "cuda")
+        t = timeit(lambda: ops.warp_bilinear(y, flow, out=o), iters=20)
+        nb = 2 * B * C * h * h * es + B * 2 * h * h * 4
+        print(f"warp_bilinear C={C} h={h}: {t*1e6:8.1f} us {nb/1e6:8.2f} MB {nb/t/1e9:8.1f} GB/s", flush=True)
+    fl = torch.rand(B, 2, 864, 864, device="cuda") * 2 - 1
+    ce = torch.randn(B, 1, 864, 864, device="cuda")
+    c16 = torch.randn(B, 1, 40, 40, device="cuda")
+    t = timeit(lambda: ops.match_finalize(fl, ce, c16), iters=20)
+    nb = B * 864 * 864 * (3 + 5) * 4
+    print(f"match_finalize 864: {t*1e6:.1f} us  {nb/t/1e9:.1f} GB/s")
+    for h in (560, 864):
+        x = torch.randn(B * h * h, 24, device="cuda").to(dt)
+        w = torch.randn(24, 24, device="cuda"); bb = torch.randn(24, device="cuda")
+        t = timeit(lambda: ops.pointwise_small(x, w, bb), iters=20)
+        print(f"pointwise_small D=24 h={h}: {t*1e6:.1f} us  {2*x.numel()*es/t/1e9:.1f} GB/s")
+        xx = x.view(B, h, h, 24); wo = torch.randn(24, 3, device="cuda"); bo = torch.randn(3, device="cuda")
+        f2 = torch.rand(B, 2, h, h, device="cuda"); c2 = torch.randn(B, 1, h, h, device="cuda")
+        t = timeit(lambda: ops.refiner_head(xx, wo, bo, f2, c2, 1e-3, 1e-3), iters=20)
+        print(f"refiner_head D=24 h={h}: {t*1e6:.1f} us  {(x.numel()*es + B*h*h*16)/t/1e9:.1f} GB/s")
+    f0 = torch.randn(16, 64, 60, 80, device="cuda"); f1 = torch.randn(16, 64, 60, 80, device="cuda")
+    for exact in (False, True):
+        t = timeit(lambda: ops.tiny_corr_posembed(f0, f1, exact=exact), iters=5, warm=2)
+        print(f"tiny_corr_posembed B=16 60x80 C=64 exact={exact}: {t*1e3:.3f} ms  {2*16*4800*4800*64/t/1e12:.1f} TFLOP/s (fp32 MFMA), {16/t:.0f} pairs/s")
     pts = torch.rand(40000, 4, device="cuda") * 2 - 1
     t = timeit(lambda: ops.kde(pts, half=True), iters=5, warm=1)
     print(f"kde N=40000: {t*1e3:.3f} ms  {40000*40000/t/1e12:.2f} T pair-exp/s")
