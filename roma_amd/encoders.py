@@ -79,11 +79,21 @@ class CNNandDinov2(nn.Module):
         return self.cnn.train(mode)
 
     def _vit(self, device):
-        v = self.dinov2_vitl14[0]
-        p = v.cls_token
-        if p.device != device or p.dtype != self.amp_dtype:
-            v = self.dinov2_vitl14[0] = v.to(device=device, dtype=self.amp_dtype).eval()
-        return v
+        """The ViT in the amp dtype on `device`.  The module in `dinov2_vitl14[0]` stays the fp32 master (so switching
+        amp_dtype never re-rounds already rounded weights); casts are cached per (device, dtype)."""
+        master = self.dinov2_vitl14[0]
+        key = (str(device), self.amp_dtype, tuple(p._version for p in master.parameters()))
+        cache = self.__dict__.setdefault("_vit_cache", {})
+        hit = cache.get(key)
+        if hit is None:
+            import copy
+            cache.clear()
+            if self.amp_dtype == torch.float32 and next(master.parameters()).device == device:
+                hit = master.eval()
+            else:
+                hit = copy.deepcopy(master).to(device=device, dtype=self.amp_dtype).eval()
+            cache[key] = hit
+        return hit
 
     @torch.no_grad()
     def forward(self, x, upsample=False):

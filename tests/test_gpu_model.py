@@ -155,6 +155,43 @@ def test_end_to_end_full_560_to_864_fp32(full_model):
     assert float(dw.median()) < 1e-5 and float(dc.median()) < 1e-4
 
 
+def test_non_square_resolution_vs_oracle(full_model):
+    """Non-square coarse / upsample resolutions (the reference's demos use upsample_res=(864,1152)): the product against
+    the CPU oracle with the same weights, fp32 mode, synthetic pair."""
+    from oracle import roma_oracle as O
+    from roma_amd.synthetic import synthetic_pair
+    _set_dtype(full_model, torch.float32)
+    lo, hi = (112, 168), (160, 240)
+    o = O.roma_model(lo, hi)
+    o.load_state_dict({k: v.cpu() for k, v in full_model.state_dict().items()})
+    o.encoder.dinov2_vitl14[0].load_state_dict({k: v.float().cpu() for k, v in full_model.encoder.dinov2_vitl14[0].state_dict().items()})
+    o.encoder.dinov2_vitl14[0].eval()
+    pair = synthetic_pair(7, lo, hi)
+    rw, rc = o.match_tensors(*pair)
+    full_model.h_resized, full_model.w_resized = lo
+    full_model.upsample_res = hi
+    try:
+        w, c = full_model.match_tensors(*(t.to(DEV) for t in pair))
+    finally:
+        full_model.h_resized = full_model.w_resized = 112
+        full_model.upsample_res = (168, 168)
+    assert w.shape == (1, 160, 480, 4) and c.shape == (1, 160, 480)
+    dw, dc = (w.cpu() - rw).abs(), (c.cpu() - rc).abs()
+    print(f"non-square fp32: warp max {float(dw.max()):.2e} frac>1e-3 {float((dw > 1e-3).float().mean()):.2e}; cert max {float(dc.max()):.2e}")
+    assert float((dw > 1e-3).float().mean()) < 5e-3 and float(dw.median()) < 1e-5 and float(dc.median()) < 1e-4
+
+
+def test_bf16_mode_runs_and_agrees_in_bulk(full_model):
+    g = H.golden("e2e_112")
+    _set_dtype(full_model, torch.bfloat16)
+    try:
+        warp, cert = full_model.match(H.asset("sacre_coeur_A.jpg"), H.asset("sacre_coeur_B.jpg"), device=DEV)
+    finally:
+        _set_dtype(full_model, torch.float32)
+    assert torch.isfinite(warp).all() and torch.isfinite(cert).all()
+    assert float((cert.cpu() - H.T(g["r112_cert"])).abs().median()) < 2e-2
+
+
 def test_end_to_end_fp16_mode_bulk_agreement(full_model):
     g = H.golden("e2e_112")
     _set_dtype(full_model, torch.float16)
