@@ -108,6 +108,16 @@ int roma_kde_density(const float* x, float* density, int N, int down, float std,
 int roma_dwconv5x5_bn_relu(const void* x, const float* w, const float* scale, const float* shift, void* y,
                            int B, int C, int H, int W, int dtype, int x_pitch, int y_pitch, void* stream);
 
+/* One whole ConvRefiner block, fused, for widths C <= 160 in fp16 / bf16 — matcher.py:77-103 (create_block) as applied
+ * 9x per refiner at matcher.py:139-140:  y = bias + relu(dwconv5x5(x, w25) * scale + shift) @ wt^T.
+ *   x, y: (B,H,W,pitch) channels-last `dtype` (C channels used; x and y must not alias);
+ *   kpad: 32 or 160, the zero-padded channel count of the weight buffers (>= C);
+ *   w25: (25, kpad) `dtype` tap-major; scale, shift, bias: (kpad) fp32; wt: (kpad, kpad) `dtype`, wt[n][k] = weight of
+ *   input channel k for output channel n (the Conv2d(D, D, 1) weight itself), all zero-padded. */
+int roma_refiner_block(const void* x, const void* w25, const float* scale, const float* shift, const void* wt,
+                       const float* bias, void* y, int B, int C, int H, int W, int kpad, int dtype, int x_pitch, int y_pitch,
+                       void* stream);
+
 /* ConvRefiner head + Decoder update fused — matcher.py:141 (out_conv, D -> 3, fp32 on d.float()) and :397-402:
  *   d = bo + x[m,:] @ wo;  flow[b,0] += sx*d0;  flow[b,1] += sy*d1;  cert_out = (cert_in ? cert_in : 0) + d2
  *   x: (B*H*W, pitch) channels-last rows of `dtype` (C channels used), wo (C,3) fp32 row-major, bo (3) fp32,

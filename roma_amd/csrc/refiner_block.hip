@@ -1,0 +1,228 @@
+// One whole ConvRefiner block for MID/NARROW widths, fused — reference: romatch/models/matcher.py:77-103 (create_block:
+// depthwise 5x5 conv -> BatchNorm(eval) -> ReLU -> 1x1 conv), applied 9x per refiner (matcher.py:139-140):
+//   t[m][k]   = relu(scale[k] * sum_{dy,dx} w25[dy*5+dx][k] * x[m + (dy-2, dx-2)][k] + shift[k])
+//   out[m][n] = bias[n] + sum_k t[m][k] * wt[k][n]
+// for channel counts C <= 160 (the D = 144 and D = 24 refiners of the two finest scales, 0.3-1.5 M pixels per map), where
+// the separate depthwise kernel + hipBLASLt GEMM spend 2.3-4x the bandwidth bound (the skinny GEMM alone runs at
+// 0.65-2 TB/s) and write + re-read the intermediate.  Here the intermediate never leaves the CU:
+//   * persistent 256-thread workgroups (one per CU) walk 16x8-pixel tiles; the 1x1 weights, depthwise weights and folded BN
+//     constants are staged in LDS once per workgroup; the input tile + 2-pixel halo once per tile;
+//   * depthwise: lane (m, kq) of a wavefront owns pixel column m of two tile rows and every 4th 8-channel packet; each
+//     LDS packet read feeds both rows; fp32 accumulate (v_fma_mix_f32 / cvt + fma);
+//   * the BN+ReLU result, packed to fp16/bf16, IS the A fragment of v_mfma_f32_16x16x32 (lane (m, kq) holds channels
+//     32 ks + 8 kq .. +8 of pixel m), so the 1x1 conv runs on the matrix cores straight out of registers;
+//   * results go through LDS for 16-byte coalesced stores.
+#include "common.h"
+
+namespace roma {
+namespace {
+
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+typedef __bf16 b8v __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float4_t mfma_blk(const u32x4& a, const u32x4& b, float4_t c, half_t) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8v, a), __builtin_bit_cast(h8v, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ float4_t mfma_blk(const u32x4& a, const u32x4& b, float4_t c, bf16_t) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8v, a), __builtin_bit_cast(b8v, b), c, 0, 0, 0);
+}
+
+struct RBParams {
+  const void* x;
+  void* y;
+  const void* w25;    // (25, Kpad) T, zero-padded
+  const void* wt;     // (Npad, Kpad) T: wt[n][k] = weight(in k -> out n), zero-padded
+  const float* scale; // (Kpad)
+  const float* shift; // (Kpad)
+  const float* bias;  // (Npad)
+  int B, H, W, C, x_pitch, y_pitch;
+  int tiles_x, tiles_y;
+};
+
+constexpr int XT = 16, YT = 8, HX = XT + 4, HY = YT + 4, NPOS = HX * HY;
+
+template <typename T, int KP>
+__global__ __launch_bounds__(256, 1) void refiner_block_kernel(RBParams p) {
+  constexpr int KPAD = 32 * KP;            // padded channel count (inputs of the 1x1)
+  constexpr int NT = KPAD / 16;            // 16-wide output tiles (outputs are padded to KPAD as well)
+  constexpr int RS = KPAD / 8 + 1;         // LDS row stride in 16-byte packets (odd: conflict-free column reads)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u32x4* s_in = reinterpret_cast<u32x4*>(smem);                 // [NPOS][RS]   input tile + halo
+  u32x4* s_pw = s_in + NPOS * RS;                               // [KPAD][RS]   1x1 weights, row = output channel
+  u32x4* s_dw = s_pw + KPAD * RS;                               // [25][KPAD/8] depthwise taps
+  float* s_cs = reinterpret_cast<float*>(s_dw + 25 * (KPAD / 8));   // scale[KPAD], shift[KPAD], bias[KPAD]
+  T* s_out = reinterpret_cast<T*>(s_in);                        // [XT*YT][OS] after the depthwise phase
+  constexpr int OS = KPAD + 8;                                  // out row stride in elements
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int m = lane & 15, kq = lane >> 4;
+  const int PKT = p.C / 8;                                      // real packets per pixel
+  const T* x = static_cast<const T*>(p.x);
+  T* y = static_cast<T*>(p.y);
+
+  // ---- once per workgroup: weights and constants ----
+  for (int i = tid; i < KPAD * (KPAD / 8); i += 256) {
+    const int n = i / (KPAD / 8), k = i % (KPAD / 8);
+    s_pw[n * RS + k] = reinterpret_cast<const u32x4*>(p.wt)[i];
+  }
+  for (int i = tid; i < 25 * (KPAD / 8); i += 256) s_dw[i] = reinterpret_cast<const u32x4*>(p.w25)[i];
+  for (int i = tid; i < KPAD; i += 256) {
+    s_cs[i] = p.scale[i];
+    s_cs[KPAD + i] = p.shift[i];
+    s_cs[2 * KPAD + i] = p.bias[i];
+  }
+  // channel padding of the input tile (packets PKT .. KPAD/8-1) stays zero for the whole kernel
+  const int ntile = p.tiles_x * p.tiles_y * p.B;
+  constexpr int NLD = (NPOS * (KPAD / 8) + 255) / 256;          // 16-byte loads per thread and tile (upper bound)
+  const int nload = NPOS * PKT;
+  u32x4 pre[NLD];
+  // The next tile's input is fetched into registers while the current one is computed (one workgroup per CU at
+  // KPAD = 160: nothing else would hide the HBM latency).  Out-of-image taps become zeros (the conv's padding).
+  auto fetch = [&](int tile) {
+    const int b = tile / (p.tiles_x * p.tiles_y);
+    const int tt = tile - b * (p.tiles_x * p.tiles_y);
+    const int ty0 = (tt / p.tiles_x) * YT, tx0 = (tt % p.tiles_x) * XT;
+    const T* xb = x + (size_t)b * p.H * p.W * p.x_pitch;
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int i = min(tid + j * 256, nload - 1);
+      const int pos = i / PKT, k = i - pos * PKT;
+      const int yy = ty0 - 2 + pos / HX, xx = tx0 - 2 + pos % HX;
+      const bool ok = yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+      const int yc = min(max(yy, 0), p.H - 1), xc = min(max(xx, 0), p.W - 1);
+      u32x4 v = *reinterpret_cast<const u32x4*>(xb + ((size_t)yc * p.W + xc) * p.x_pitch + k * 8);
+      if (!ok) v = u32x4{0, 0, 0, 0};
+      pre[j] = v;
+    }
+  };
+  // channel padding of the input tile (packets PKT .. KPAD/8-1) is written once and stays zero
+  for (int i = tid; i < NPOS * (KPAD / 8 - PKT); i += 256) {
+    const int pos = i / (KPAD / 8 - PKT), k = PKT + i % (KPAD / 8 - PKT);
+    s_in[pos * RS + k] = u32x4{0, 0, 0, 0};
+  }
+  if ((int)blockIdx.x < ntile) fetch(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const int b = tile / (p.tiles_x * p.tiles_y);
+    const int tt = tile - b * (p.tiles_x * p.tiles_y);
+    const int ty0 = (tt / p.tiles_x) * YT, tx0 = (tt % p.tiles_x) * XT;
+    __syncthreads();                                            // previous tile's stores have read s_out
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int i = tid + j * 256;
+      if (i < nload) {
+        const int pos = i / PKT, k = i - pos * PKT;
+        s_in[pos * RS + k] = pre[j];
+      }
+    }
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntile) fetch(tile + gridDim.x);
+    // ---- depthwise 5x5 + BN + ReLU for pixel column m, tile rows 2wv and 2wv+1 ----
+    u32x4 afrag[2][KP];
+#pragma unroll
+    for (int ks = 0; ks < KP; ++ks) {
+      const int pk = 4 * ks + kq;
+      float acc0[8], acc1[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc0[e] = acc1[e] = 0.f;
+#pragma unroll
+      for (int dy = 0; dy < 6; ++dy) {
+#pragma unroll
+        for (int dx = 0; dx < 5; ++dx) {
+          float fi[8];
+          unpack16<T>(s_in[((2 * wv + dy) * HX + m + dx) * RS + pk], fi);
+          if (dy < 5) {
+            float fw[8];
+            unpack16<T>(s_dw[(dy * 5 + dx) * (KPAD / 8) + pk], fw);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc0[e] = __builtin_fmaf(fi[e], fw[e], acc0[e]);
+          }
+          if (dy >= 1) {
+            float fw[8];
+            unpack16<T>(s_dw[((dy - 1) * 5 + dx) * (KPAD / 8) + pk], fw);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc1[e] = __builtin_fmaf(fi[e], fw[e], acc1[e]);
+          }
+        }
+      }
+      float v0[8], v1[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float sc = s_cs[pk * 8 + e], sh = s_cs[KPAD + pk * 8 + e];
+        v0[e] = fmaxf(__builtin_fmaf(acc0[e], sc, sh), 0.f);
+        v1[e] = fmaxf(__builtin_fmaf(acc1[e], sc, sh), 0.f);
+      }
+      afrag[0][ks] = pack16<T>(v0);
+      afrag[1][ks] = pack16<T>(v1);
+    }
+    // ---- 1x1 conv on the matrix cores ----
+    float4_t acc[2][NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[0][nt] = acc[1][nt] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+      for (int ks = 0; ks < KP; ++ks) {
+        const u32x4 bfrag = s_pw[(nt * 16 + m) * RS + 4 * ks + kq];
+        acc[0][nt] = mfma_blk(afrag[0][ks], bfrag, acc[0][nt], T{});
+        acc[1][nt] = mfma_blk(afrag[1][ks], bfrag, acc[1][nt], T{});
+      }
+    }
+    __syncthreads();                                            // every wavefront is done with s_in
+    // ---- accumulators (+bias) -> LDS [pixel][channel]; lane (n = m, mq = kq) holds pixels 4mq..4mq+3 of each row ----
+#pragma unroll
+    for (int row = 0; row < 2; ++row)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int ch = nt * 16 + m;
+        const float bsv = s_cs[2 * KPAD + ch];
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4)
+          s_out[((2 * wv + row) * XT + 4 * kq + r4) * OS + ch] = from_f32<T>(acc[row][nt][r4] + bsv);
+      }
+    __syncthreads();
+    T* yb = y + (size_t)b * p.H * p.W * p.y_pitch;
+    for (int i = tid; i < XT * YT * PKT; i += 256) {
+      const int pix = i / PKT, k = i - pix * PKT;
+      const int yy = ty0 + pix / XT, xx = tx0 + pix % XT;
+      if (yy < p.H && xx < p.W)
+        *reinterpret_cast<u32x4*>(yb + ((size_t)yy * p.W + xx) * p.y_pitch + k * 8) = *reinterpret_cast<const u32x4*>(s_out + pix * OS + k * 8);
+    }
+  }
+}
+
+template <typename T, int KP>
+int launch_rb(const RBParams& p, hipStream_t s) {
+  constexpr int KPAD = 32 * KP, RS = KPAD / 8 + 1;
+  const size_t smem = (size_t)(NPOS * RS + KPAD * RS + 25 * (KPAD / 8)) * 16 + 3 * KPAD * 4;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(refiner_block_kernel<T, KP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) { set_error("roma_refiner_block: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    attr_done = true;
+  }
+  const int ntile = p.B * p.tiles_x * p.tiles_y;
+  const int per_cu = KP == 1 ? 4 : 1;                          // LDS footprint: ~25 KB (KP=1) or ~140 KB (KP=5)
+  const int grid = ntile < 256 * per_cu ? ntile : 256 * per_cu;
+  hipLaunchKernelGGL((refiner_block_kernel<T, KP>), dim3(grid), dim3(256), smem, s, p);
+  ROMA_CHECK_LAUNCH();
+}
+
+}  // namespace
+}  // namespace roma
+
+using namespace roma;
+
+extern "C" int roma_refiner_block(const void* x, const void* w25, const float* scale, const float* shift, const void* wt,
+                                  const float* bias, void* y, int B, int C, int H, int W, int kpad, int dtype, int x_pitch, int y_pitch,
+                                  void* stream) {
+  ROMA_REQUIRE(x && w25 && scale && shift && wt && bias && y, ROMA_E_ARG, "roma_refiner_block: null pointer");
+  ROMA_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && x_pitch >= C && y_pitch >= C, ROMA_E_SHAPE, "roma_refiner_block: bad shape");
+  ROMA_REQUIRE(dtype == ROMA_F16 || dtype == ROMA_BF16, ROMA_E_DTYPE, "roma_refiner_block: fp16 / bf16 only (the fp32 parity mode uses the separate kernels)");
+  ROMA_REQUIRE((kpad == 32 || kpad == 160) && C <= kpad && C % 8 == 0, ROMA_E_UNSUPPORTED, "roma_refiner_block: C=%d, kpad=%d (kpad must be 32 or 160, C a multiple of 8)", C, kpad);
+  ROMA_REQUIRE(x_pitch % 8 == 0 && y_pitch % 8 == 0 && aligned16(x) && aligned16(y) && aligned16(w25) && aligned16(wt), ROMA_E_ALIGN,
+               "roma_refiner_block: pitches must be multiples of 8 and bases 16-byte aligned");
+  RBParams p{x, y, w25, wt, scale, shift, bias, B, H, W, C, x_pitch, y_pitch, (W + XT - 1) / XT, (H + YT - 1) / YT};
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == ROMA_F16) return kpad == 32 ? launch_rb<half_t, 1>(p, s) : launch_rb<half_t, 5>(p, s);
+  return kpad == 32 ? launch_rb<bf16_t, 1>(p, s) : launch_rb<bf16_t, 5>(p, s);
+}

@@ -14,6 +14,11 @@ from .transformer import DinoViT
 VGG19_CFG = [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M"]
 
 
+def _ver(t):
+    """In-place-update counter used as a cache key (inference tensors do not have one)."""
+    return 0 if t.is_inference() else t._version
+
+
 class VGG19(nn.Module):
     """Parameters live in `layers.{0..39}` exactly like torchvision's vgg19_bn().features[:40] (encoders.py:64)."""
 
@@ -31,7 +36,7 @@ class VGG19(nn.Module):
 
     def fold(self, dtype):
         """conv+BN(eval) -> one conv: w' = w*g/sqrt(var+eps), b' = (b-mean)*g/sqrt(var+eps)+beta.  Cached."""
-        key = (dtype, self.layers[0].weight.device, tuple(p._version for p in self.parameters()))
+        key = (dtype, self.layers[0].weight.device, tuple(_ver(p) for p in self.parameters()))
         if self._folded is not None and self._folded[0] == key:
             return self._folded[1]
         plan = []
@@ -82,7 +87,7 @@ class CNNandDinov2(nn.Module):
         """The ViT in the amp dtype on `device`.  The module in `dinov2_vitl14[0]` stays the fp32 master (so switching
         amp_dtype never re-rounds already rounded weights); casts are cached per (device, dtype)."""
         master = self.dinov2_vitl14[0]
-        key = (str(device), self.amp_dtype, tuple(p._version for p in master.parameters()))
+        key = (str(device), self.amp_dtype, tuple(_ver(p) for p in master.parameters()))
         cache = self.__dict__.setdefault("_vit_cache", {})
         hit = cache.get(key)
         if hit is None:
@@ -91,7 +96,8 @@ class CNNandDinov2(nn.Module):
             if self.amp_dtype == torch.float32 and next(master.parameters()).device == device:
                 hit = master.eval()
             else:
-                hit = copy.deepcopy(master).to(device=device, dtype=self.amp_dtype).eval()
+                with torch.inference_mode(False), torch.no_grad():      # ordinary tensors even when called under inference_mode
+                    hit = copy.deepcopy(master).to(device=device, dtype=self.amp_dtype).eval()
             cache[key] = hit
         return hit
 

@@ -39,12 +39,18 @@ def pixel_grid(b, h, w, device):
 
 
 def _params_version(module):
-    return tuple((p.data_ptr(), p._version) for p in list(module.parameters()) + list(module.buffers()))
+    return tuple((p.data_ptr(), 0 if p.is_inference() else p._version) for p in list(module.parameters()) + list(module.buffers()))
 
 
 # ------------------------------------------------------------------------------------------------
 # ConvRefiner — matcher.py:17-143
 # ------------------------------------------------------------------------------------------------
+def _zero_pad(t, *shape):
+    out = torch.zeros(shape, dtype=t.dtype, device=t.device)
+    out[tuple(slice(0, s) for s in t.shape)] = t
+    return out
+
+
 class ConvRefiner(nn.Module):
     """x, warped y, displacement embedding and local correlation are assembled in ONE channels-last buffer
     (pitch padded to 8 channels) by four kernels writing channel slices; every block is the fused
@@ -75,6 +81,10 @@ class ConvRefiner(nn.Module):
         D = self.in_dim
         Dp = _round_up(D, 8)
         dev = self.out_conv.weight.device
+        # whole-block fusion (ops.refiner_block): measured 1.8x faster than dwconv + pointwise at D = 24, on par at D = 144
+        # (LDS-read and VALU bound there) -> narrow refiners only unless ROMA_FUSED_BLOCK=160
+        fuse_max = int(os.environ.get("ROMA_FUSED_BLOCK", "32"))
+        fused = Dp <= min(fuse_max, 160) and dtype in (torch.float16, torch.bfloat16)
         blocks = []
         for blk in [self.block1] + list(self.hidden_blocks):
             dw, bn, _, pw = blk
@@ -90,14 +100,19 @@ class ConvRefiner(nn.Module):
             wt[:D, :D] = pw.weight.float().reshape(D, D).t()            # (in, out): X @ wt
             b = torch.zeros(Dp, device=dev)
             b[:D] = pw.bias.float()
+            if fused:
+                # one kernel per block (ops.refiner_block): weights zero-padded to kpad channels, 1x1 weight as [out][in]
+                kp = 32 if Dp <= 32 else 160
+                blocks.append((_zero_pad(w25, 25, kp).to(dtype), _zero_pad(scale, kp), _zero_pad(shift, kp),
+                               _zero_pad(wt.t(), kp, kp).to(dtype), _zero_pad(b, kp)))
             # narrow refiners (Dp <= 32): the 1x1 conv is a streaming op -> own kernel with fp32 weights; else a library GEMM
-            if Dp <= 32:
+            elif Dp <= 32:
                 blocks.append((w25.contiguous(), scale, shift, wt.contiguous(), b.contiguous()))
             else:
                 blocks.append((w25.contiguous(), scale, shift, wt.to(dtype).contiguous(), b.to(dtype)))
         wo = torch.zeros(Dp, self.out_dim, device=dev)
         wo[:D] = self.out_conv.weight.float().reshape(self.out_dim, D).t()
-        prep = dict(D=D, Dp=Dp, blocks=blocks, wo=wo.contiguous(), bo=self.out_conv.bias.float(),
+        prep = dict(D=D, Dp=Dp, fused=fused, blocks=blocks, wo=wo.contiguous(), bo=self.out_conv.bias.float(),
                     we=self.disp_emb.weight.float().reshape(-1, 2).contiguous(), be=self.disp_emb.bias.float())
         self._prep = (key, prep)
         return prep
@@ -124,6 +139,12 @@ class ConvRefiner(nn.Module):
             ops.local_correlation(d[:, :C], yy, r, flow=flow, out=d[:, 2 * C + E:D])           # :121-125
         M = B * h * w
         cur = buf
+        if P["fused"]:
+            nxt = torch.empty_like(buf)
+            for (w25, scale, shift, wt, b) in P["blocks"]:                                     # :139-140
+                ops.refiner_block(cur, w25, scale, shift, wt, b, Dp, out=nxt)
+                cur, nxt = nxt, cur
+            return cur, P
         for (w25, scale, shift, wt, b) in P["blocks"]:                                         # :139-140
             t = ops.dwconv5x5_bn_relu(cur.permute(0, 3, 1, 2), w25, scale, shift)
             rows = t.permute(0, 2, 3, 1).reshape(M, Dp)

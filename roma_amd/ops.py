@@ -336,6 +336,22 @@ def dwconv5x5_bn_relu(x, w25, scale, shift, out=None):
     return out
 
 
+def refiner_block(x_nhwc, w25, scale, shift, wt, bias, C, out=None):
+    """One fused ConvRefiner block (depthwise 5x5 + BN + ReLU + 1x1 conv, matcher.py:77-103) for C <= 160, fp16/bf16.
+    x_nhwc: (B,h,w,pitch) contiguous; w25 (25,kpad), wt (kpad,kpad) [out][in] in x's dtype; scale/shift/bias (kpad) fp32."""
+    _need_gpu(x_nhwc, w25, scale, shift, wt, bias, out)
+    B, h, w, pitch = x_nhwc.shape
+    kpad = wt.shape[0]
+    assert x_nhwc.is_contiguous() and wt.is_contiguous() and w25.is_contiguous() and wt.dtype == x_nhwc.dtype == w25.dtype
+    assert w25.shape == (25, kpad) and wt.shape == (kpad, kpad) and scale.numel() == shift.numel() == bias.numel() == kpad
+    if out is None:
+        out = torch.empty_like(x_nhwc)
+    assert out.is_contiguous() and out.shape == x_nhwc.shape and out.data_ptr() != x_nhwc.data_ptr()
+    check(_lib.load().roma_refiner_block(_p(x_nhwc), _p(w25), _p(scale), _p(shift), _p(wt), _p(bias), _p(out), B, C, h, w, kpad,
+                                         _dt(x_nhwc), pitch, pitch, _stream()), "roma_refiner_block")
+    return out
+
+
 def refiner_head(x_nhwc, wo, bo, flow, certainty, sx, sy, want_delta=False):
     """out_conv (D -> 3, fp32) of the last refiner block fused with the flow / certainty update (matcher.py:141, 397-402).
     x_nhwc: (B,h,w,pitch) channels-last activation; wo (C,3) fp32; bo (3) fp32; flow (B,2,h,w) fp32 is updated IN PLACE;

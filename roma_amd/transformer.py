@@ -107,7 +107,7 @@ class DinoViT(nn.Module):
 
     def pos_encoding(self, w, h, dtype):
         """dinov2.py:166-190: bicubic resize of the 37x37 table with scale_factor (w0+0.1)/37; cached per input size."""
-        key = (w, h, dtype, self.pos_embed.device, self.pos_embed._version)
+        key = (w, h, dtype, self.pos_embed.device, 0 if self.pos_embed.is_inference() else self.pos_embed._version)
         hit = self._pos_cache.get(key)
         if hit is not None:
             return hit

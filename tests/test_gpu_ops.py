@@ -220,7 +220,12 @@ def test_spd_solve_against_fp64():
         x = torch.nn.functional.normalize(torch.randn(2, n, 64), dim=-1)
         K = torch.exp((x @ x.transpose(1, 2) - 1) / 0.2) + 0.1 * torch.eye(n)
         F = torch.randn(2, n, m)
-        ref = torch.linalg.solve(K.double(), F.double())
+        nt = torch.get_num_threads()
+        torch.set_num_threads(1)        # multithreaded oneMKL getrf hangs on the GPU boxes' host CPUs (see oracle._inv_single_thread)
+        try:
+            ref = torch.linalg.solve(K.double(), F.double())
+        finally:
+            torch.set_num_threads(nt)
         X = _ops().spd_solve(K.to(DEV).contiguous(), F.to(DEV))
         assert float((X.cpu().double() - ref).abs().max()) < 2e-5 * float(ref.abs().max())
 
@@ -322,3 +327,33 @@ def test_tiny_corr_posembed_full_size():
     cv = O.tiny_corr_volume(f0, f1)
     assert maxerr(_ops().tiny_corr_posembed(f0.to(DEV), f1.to(DEV), exact=True), O.tiny_pos_embed(cv, True)) < 2e-5
     assert maxerr(_ops().tiny_corr_posembed(f0.to(DEV), f1.to(DEV), exact=False), O.tiny_pos_embed(cv, False)) < 2e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("C,kpad,B,H,W", [(144, 160, 1, 37, 45), (24, 32, 2, 19, 50), (144, 160, 2, 8, 16), (32, 32, 1, 64, 64), (160, 160, 1, 23, 17)])
+def test_refiner_block_vs_torch(dtype, C, kpad, B, H, W):
+    """Fused ConvRefiner block vs conv2d(groups)+BN+ReLU+1x1 in fp32 on the same (rounded) operands — matcher.py:77-103."""
+    import torch.nn.functional as F
+    ops, dev = _ops(), DEV
+    g = torch.Generator().manual_seed(C * 1000 + H)
+    x = torch.randn(B, H, W, C, generator=g).to(dev).to(dtype)
+    w25 = torch.zeros(25, kpad)
+    w25[:, :C] = torch.randn(25, C, generator=g) * 0.2
+    scale = torch.zeros(kpad)
+    shift = torch.zeros(kpad)
+    bias = torch.zeros(kpad)
+    scale[:C] = torch.rand(C, generator=g) + 0.5
+    shift[:C] = torch.randn(C, generator=g) * 0.3
+    bias[:C] = torch.randn(C, generator=g) * 0.1
+    wt = torch.zeros(kpad, kpad)
+    wt[:C, :C] = torch.randn(C, C, generator=g) / C ** 0.5
+    w25d, wtd = w25.to(dev).to(dtype), wt.to(dev).to(dtype)
+    out = ops.refiner_block(x, w25d, scale.to(dev), shift.to(dev), wtd, bias.to(dev), C)
+    # fp32 reference on the rounded operands; the intermediate is rounded to `dtype` as in the kernel (and the reference's autocast)
+    xf = x.float().permute(0, 3, 1, 2)
+    t = F.conv2d(xf, w25d.float()[:, :C].t().reshape(C, 1, 5, 5), padding=2, groups=C)
+    t = torch.relu(t * scale[:C].to(dev).view(1, C, 1, 1) + shift[:C].to(dev).view(1, C, 1, 1)).to(dtype).float()
+    ref = torch.einsum("bkhw,nk->bhwn", t, wtd.float()[:C, :C]) + bias[:C].to(dev)
+    tol = 4e-3 if dtype == torch.float16 else 3e-2
+    err = (out.float() - ref).abs().max().item()
+    assert err < tol * max(1.0, ref.abs().max().item()), err
