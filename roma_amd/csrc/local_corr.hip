@@ -526,8 +526,8 @@ int launch_lc_nhwc(LCParams p, hipStream_t stream) {
 // A fragment (the group's f0 rows) is read once per chunk and reused for every block; each B fragment is one
 // ds_read_b128 of 16 consecutive staged rows.  Rows are XOR-swizzled by (row>>2)&1 and the four K-slices are assigned to
 // the lane quarters in the order (0,2,1,3): with the fixed ds_read_b128 lane groups this is bank-conflict free for any
-// row base (exhaustive search, tools/scratch).  The 16x16 results go through LDS (per pixel [row][col] images) for the
-// 4-tap blend.  Only 1/4-1/3 of the computed products are used (every pixel needs (2r+2)^2 of the union's positions),
+// row base (exhaustive search, tools/scratch).  Each lane scatters the products that fall in its pixels' own windows
+// straight into the per-pixel (2r+2)^2 images the 4-tap blend reads.  Only 1/4-1/3 of the computed products are used (every pixel needs (2r+2)^2 of the union's positions),
 // which the 16x MFMA rate absorbs.  Tiles whose groups are not compact (incoherent flow) use per-pixel patches on the
 // VALU (mode B of the kernel above, same staging).
 // ------------------------------------------------------------------------------------------------------------------
@@ -540,7 +540,6 @@ template <int R> struct LCM {
   static constexpr int WC = 16 * NRUN;                       // union columns a group may span
   static constexpr int GHMAX = N2 + 10;                      // union rows a group may span
   static constexpr int NB = (GHMAX * NRUN + WPG - 1) / WPG;  // accumulator blocks per wavefront
-  static constexpr int MS = GHMAX * WC + 4;                  // floats per pixel in the exchange buffer (= 4 mod 8: no write conflicts)
   static constexpr int MAXR = R <= 3 ? 384 : 704;            // staged rows
 };
 
@@ -560,18 +559,17 @@ template <typename T, int R>
 __global__ __launch_bounds__(kThreads, 2) void local_corr_mfma_kernel(LCParams p) {
   using M = LCM<R>;
   constexpr int NG = M::NG, TP = M::TP, TW = M::TW, TH = M::TH, WPG = M::WPG, NRUN = M::NRUN, WC = M::WC;
-  constexpr int GHMAX = M::GHMAX, NB = M::NB, MS = M::MS, MAXR = M::MAXR;
+  constexpr int GHMAX = M::GHMAX, NB = M::NB, MAXR = M::MAXR;
   constexpr int N1 = 2 * R + 1, N2 = 2 * R + 2, Q = N2 * N2, K = N1 * N1;
   constexpr int NIT = (Q + 15) / 16, QP = NIT * 16;
   constexpr int E16 = 8, PK = 4, CC = PK * E16;
   constexpr int SB = pow2_floor(MAXR / QP);
   constexpr int NL = ((TP + MAXR) * PK + kThreads - 1) / kThreads;
   constexpr int ZROW = NL * (kThreads / PK);
-  constexpr int BODY16 = (NL * kThreads + 16 * PK) > (NG * 16 * MS / 4 + 1) ? (NL * kThreads + 16 * PK) : (NG * 16 * MS / 4 + 1);
+  constexpr int BODY16 = NL * kThreads + 16 * PK;          // staged rows + 16 zero rows
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  u32x4* s_rows = reinterpret_cast<u32x4*>(smem);             // staged rows; later the MFMA result exchange S
-  float* s_S = reinterpret_cast<float*>(smem);
+  u32x4* s_rows = reinterpret_cast<u32x4*>(smem);             // staged rows
   float* s_D = reinterpret_cast<float*>(s_rows + BODY16);     // [TP][Q+1], mode B only
   int* s_meta = reinterpret_cast<int*>(s_D + TP * (Q + 1));   // [0..3] tile box, [8+4g ..] group boxes
   int* s_x0 = s_meta + 8 + 4 * NG;
@@ -587,14 +585,17 @@ __global__ __launch_bounds__(kThreads, 2) void local_corr_mfma_kernel(LCParams p
   const int ty0 = (t / p.tiles_x) * TH, tx0 = (t % p.tiles_x) * TW;
   const int H = p.H, W = p.W;
 
-  if (tid < 8 + 4 * NG) s_meta[tid] = ((tid & 3) < 2) ? 0x7fffffff : -0x7fffffff;
   for (int i = tid; i < 16 * PK; i += kThreads) s_rows[ZROW * PK + i] = u32x4{0, 0, 0, 0};
-  __syncthreads();
-  if (tid < TP) {
+  for (int i = tid; i < TP * (Q + 1); i += kThreads) s_D[i] = 0.f;
+  // ---- per-pixel targets and the tile / group boxes: the TP pixel threads are the low lanes of wavefront 0, so the
+  // boxes are wavefront shuffles (the first version used 8 LDS atomics per pixel + two more barriers: 21 % of the
+  // kernel in the ablation of DESIGN.md §3.1) ----
+  if (wave == 0) {
     const int y = ty0 + tid / TW, x = tx0 + tid % TW;
     int x0 = 0, y0 = 0;
     float ax = 0.f, ay = 0.f;
-    if (y < H && x < W) {
+    int lox = 0x3fffffff, loy = 0x3fffffff, hix = -0x3fffffff, hiy = -0x3fffffff;
+    if (tid < TP && y < H && x < W) {
       float fx, fy;
       if (p.flow) {
         fx = p.flow[((size_t)(b * 2 + 0) * H + y) * W + x];
@@ -611,18 +612,37 @@ __global__ __launch_bounds__(kThreads, 2) void local_corr_mfma_kernel(LCParams p
       ay = py - fy0;
       x0 = (int)fx0;
       y0 = (int)fy0;
-      const int lox = max(x0 - R, 0), hix = min(x0 + R + 1, W - 1);
-      const int loy = max(y0 - R, 0), hiy = min(y0 + R + 1, H - 1);
-      if (lox <= hix && loy <= hiy) {
-        int* gm = s_meta + 8 + 4 * ((tid % TW) / 4);
-        atomicMin(&s_meta[0], lox); atomicMin(&s_meta[1], loy); atomicMax(&s_meta[2], hix); atomicMax(&s_meta[3], hiy);
-        atomicMin(&gm[0], lox); atomicMin(&gm[1], loy); atomicMax(&gm[2], hix); atomicMax(&gm[3], hiy);
-      }
+      const int a0 = max(x0 - R, 0), a1 = min(x0 + R + 1, W - 1);
+      const int b0 = max(y0 - R, 0), b1 = min(y0 + R + 1, H - 1);
+      if (a0 <= a1 && b0 <= b1) { lox = a0; hix = a1; loy = b0; hiy = b1; }
     }
-    s_x0[tid] = x0;
-    s_y0[tid] = y0;
-    s_ax[tid] = ax;
-    s_ay[tid] = ay;
+    if (tid < TP) {
+      s_x0[tid] = x0;
+      s_y0[tid] = y0;
+      s_ax[tid] = ax;
+      s_ay[tid] = ay;
+    }
+    // pixel tid = (ty, tx) = (tid / TW, tid % TW); its 4x4 group is tx >> 2.  Reduce over every lane bit except the
+    // group bit(s) first (group boxes), then over those (tile box).  Lanes >= TP carry neutral values.
+    constexpr int GMASK = (TW - 1) & ~3;                     // lane bits that select the group: 4 for TW = 8, 0 for TW = 4
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1)
+      if (!(o & GMASK)) {
+        lox = min(lox, __shfl_xor(lox, o, 64)); loy = min(loy, __shfl_xor(loy, o, 64));
+        hix = max(hix, __shfl_xor(hix, o, 64)); hiy = max(hiy, __shfl_xor(hiy, o, 64));
+      }
+    // lane 4g holds group g's box (tx = 4g, ty = 0)
+    if ((tid & ~GMASK) == 0 && tid < TW) {
+      int* gm = s_meta + 8 + 4 * (tid >> 2);
+      gm[0] = lox; gm[1] = loy; gm[2] = hix; gm[3] = hiy;
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1)
+      if (o & GMASK) {
+        lox = min(lox, __shfl_xor(lox, o, 64)); loy = min(loy, __shfl_xor(loy, o, 64));
+        hix = max(hix, __shfl_xor(hix, o, 64)); hiy = max(hiy, __shfl_xor(hiy, o, 64));
+      }
+    if (tid == 0) { s_meta[0] = lox; s_meta[1] = loy; s_meta[2] = hix; s_meta[3] = hiy; }
   }
   __syncthreads();
   const int bx0 = s_meta[0], by0 = s_meta[1];
@@ -643,10 +663,13 @@ __global__ __launch_bounds__(kThreads, 2) void local_corr_mfma_kernel(LCParams p
 
   if (eligible) {
     // =========================== matrix-core path ===========================
+    const float inv_bw = 1.0f / (float)bw;
     const T* src[NL];
     const int used_rows = TP + bw * bh;
+    const int nl_used = (((used_rows + 15) & ~15) * PK + kThreads - 1) / kThreads;
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
+      if (l >= nl_used) { src[l] = f0; continue; }            // never issued
       const int slot = l * kThreads + tid;
       const int row = slot >> 2;
       const int k = (slot & 3) ^ ((row >> 2) & 1);
@@ -658,7 +681,7 @@ __global__ __launch_bounds__(kThreads, 2) void local_corr_mfma_kernel(LCParams p
         x = min(x, W - 1);
       } else if (row < used_rows) {
         const int rr = row - TP;
-        const int ry = rr / bw;
+        const int ry = min((int)(((float)rr + 0.5f) * inv_bw), bh - 1);   // rr / bw, exact for these small integers
         y = by0 + ry;
         x = bx0 + rr - ry * bw;
         base = f1;
@@ -666,12 +689,11 @@ __global__ __launch_bounds__(kThreads, 2) void local_corr_mfma_kernel(LCParams p
       }
       src[l] = base + ((size_t)y * W + x) * pitch + k * E16;
     }
-    const int nl_used = (((used_rows + 15) & ~15) * PK + kThreads - 1) / kThreads;
     const int gi = wave / WPG, sub = wave % WPG;
     const int* gm = s_meta + 8 + 4 * gi;
     const bool gempty = gm[2] < gm[0] || gm[3] < gm[1];
     const int gx0 = gm[0], gy0 = gm[1];
-    const int gh = gempty ? 0 : gm[3] - gy0 + 1;
+    const int gh = gempty ? 0 : gm[3] - gy0 + 1, gw = gempty ? 0 : gm[2] - gx0 + 1;
     const int n = lane & 15, kg = lane >> 4;
     const int ks = (kg == 1) ? 2 : (kg == 2 ? 1 : kg);          // K-slice of this lane quarter: (0,2,1,3)
     int bidx[NB];
@@ -696,15 +718,30 @@ __global__ __launch_bounds__(kThreads, 2) void local_corr_mfma_kernel(LCParams p
       for (int j = 0; j < NB; ++j) acc[j] = mfma16(a, s_rows[bidx[j]], acc[j], T{});
       __syncthreads();
     }
-    // accumulators -> S[g][m][ry*WC + col] (col = 16*run + n, m = 4*kg + reg)
+    // accumulators -> the per-pixel window images s_D[pix][dy*N2+dx] directly: lane (n, kg) of block (ry, run) holds the
+    // products of pixels m = 4kg..4kg+3 of the group with union position (gy0+ry, gx0+16run+n); each pixel keeps the
+    // (2r+2)^2 of them that fall in its own window (positions outside the image are never written: s_D starts at 0)
+    {
+      int wx[4], wy[4], pixs[4];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      const int blk = sub + WPG * j;
-      if (blk < gh * NRUN) {
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int m = 4 * kg + r4;
+        pixs[r4] = (m >> 2) * TW + 4 * gi + (m & 3);
+        wx[r4] = s_x0[pixs[r4]] - R;
+        wy[r4] = s_y0[pixs[r4]] - R;
+      }
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int blk = sub + WPG * j;
         const int ry = blk / NRUN, run = blk - ry * NRUN;
-        float* dst = s_S + (size_t)(gi * 16 + 4 * kg) * MS + ry * WC + 16 * run + n;
+        if (blk < gh * NRUN && 16 * run + n < gw) {             // inside the group's (image-clamped) box: the rest of a
+          const int ya = gy0 + ry, xa = gx0 + 16 * run + n;     // 16-wide run wraps into other rows / unstaged LDS
 #pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) dst[r4 * MS] = acc[j][r4] * p.scale;
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const int dy = ya - wy[r4], dx = xa - wx[r4];
+            if (dy >= 0 && dy < N2 && dx >= 0 && dx < N2) s_D[pixs[r4] * (Q + 1) + dy * N2 + dx] = acc[j][r4] * p.scale;
+          }
+        }
       }
     }
     __syncthreads();
@@ -713,18 +750,11 @@ __global__ __launch_bounds__(kThreads, 2) void local_corr_mfma_kernel(LCParams p
       if (p.out_nhwc) { pix = e / K; k = e - pix * K; } else { k = e / TP; pix = e - k * TP; }
       const int y = ty0 + pix / TW, x = tx0 + pix % TW;
       if (y >= H || x >= W) continue;
-      const int g = (pix % TW) >> 2;
-      const int* gq = s_meta + 8 + 4 * g;
-      const float* Sp = s_S + (size_t)frow(pix) * MS;
       const int iy = k / N1, ix = k - iy * N1;
-      const int yy = s_y0[pix] - R + iy, xx = s_x0[pix] - R + ix;
       const float ax = s_ax[pix], ay = s_ay[pix];
-      auto D = [&](int jj, int ii) -> float {
-        const int ya = yy + jj, xa = xx + ii;
-        return (ya >= 0 && ya < H && xa >= 0 && xa < W) ? Sp[(ya - gq[1]) * WC + (xa - gq[0])] : 0.f;
-      };
-      const float d00 = D(0, 0), d01 = D(0, 1), d10 = D(1, 0), d11 = D(1, 1);
-      const float top = d00 + ax * (d01 - d00), bot = d10 + ax * (d11 - d10);
+      const float* d = s_D + pix * (Q + 1) + iy * N2 + ix;
+      const float top = d[0] + ax * (d[1] - d[0]);
+      const float bot = d[N2] + ax * (d[N2 + 1] - d[N2]);
       out[feat_off(p.out_nhwc, b, k, y, x, p.out_pitch, H, W)] = from_f32<T>(top + ay * (bot - top));
     }
     return;
@@ -830,7 +860,7 @@ int launch_lc_mfma(LCParams p, hipStream_t stream) {
   using M = LCM<R>;
   constexpr int Q = (2 * R + 2) * (2 * R + 2);
   constexpr int NL = ((M::TP + M::MAXR) * 4 + kThreads - 1) / kThreads;
-  constexpr int BODY16 = (NL * kThreads + 64) > (M::NG * 16 * M::MS / 4 + 1) ? (NL * kThreads + 64) : (M::NG * 16 * M::MS / 4 + 1);
+  constexpr int BODY16 = NL * kThreads + 64;
   p.tiles_x = (p.W + M::TW - 1) / M::TW;
   p.tiles_y = (p.H + M::TH - 1) / M::TH;
   p.max_rows = M::MAXR;

@@ -76,6 +76,40 @@ def test_local_corr_full_sizes_vs_oracle(shape):
     assert maxerr(out, ref) < 5e-5
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 512, 40, 40, 7), (1, 512, 70, 70, 3), (1, 256, 140, 140, 2), (1, 64, 37, 53, 2), (2, 32, 21, 18, 3),
+                                   (1, 96, 30, 44, 7), (1, 256, 216, 216, 2)])
+@pytest.mark.parametrize("kind", ["coherent", "adversarial", "mixed"])
+def test_local_corr_matrix_core_path_vs_fp32_kernel(shape, kind, dtype):
+    """16-bit channels-last inputs take the MFMA / per-pixel-patch kernel; the fp32 kernel (checked against the oracle
+    above) on the SAME rounded inputs is the reference.  'mixed' = coherent flow with a block of adversarial targets and
+    NaN / far-out-of-range entries, so one launch exercises every per-tile mode and the image borders."""
+    B, C, h, w, r = shape
+    ops = _ops()
+    f0 = H.T(R.normal(f"lcm.{shape}.f0", (B, C, h, w))).to(dtype)
+    f1 = H.T(R.normal(f"lcm.{shape}.f1", (B, C, h, w))).to(dtype)
+    if kind == "coherent":
+        flow = R.coherent_flow(f"lcm.{shape}.flow", B, h, w)
+    elif kind == "adversarial":
+        flow = R.adversarial_flow(f"lcm.{shape}.flow", B, h, w)
+    else:
+        flow = R.coherent_flow(f"lcm.{shape}.flow", B, h, w)
+        adv = R.adversarial_flow(f"lcm.{shape}.adv", B, h, w)
+        flow[:, :, h // 3: 2 * h // 3, w // 4: w // 2] = adv[:, :, h // 3: 2 * h // 3, w // 4: w // 2]
+        flow[:, 0, 0, 0] = float("nan")
+        flow[:, 1, -1, -1] = 1e30
+        flow[:, :, 1, 2] = -7.0
+    flow = H.T(flow, DEV)
+    a16 = f0.to(DEV).contiguous(memory_format=torch.channels_last)
+    b16 = f1.to(DEV).contiguous(memory_format=torch.channels_last)
+    out = ops.local_correlation(a16, b16, r, flow=flow)
+    ref = ops.local_correlation(a16.float().contiguous(memory_format=torch.channels_last),
+                                b16.float().contiguous(memory_format=torch.channels_last), r, flow=flow)
+    assert out.dtype == dtype and torch.isfinite(out.float()).all()
+    tol = (2 ** -10 if dtype == torch.float16 else 2 ** -7) * max(1.0, float(ref.abs().max()))
+    assert maxerr(out, ref) <= tol
+
+
 def test_local_corr_full_size_golden_l16():
     g = H.golden("local_corr")
     B, C, h, w, r = 2, 512, 40, 40, 7
