@@ -532,7 +532,7 @@ int launch_lc_nhwc(LCParams p, hipStream_t stream) {
 // VALU (mode B of the kernel above, same staging).
 // ------------------------------------------------------------------------------------------------------------------
 template <int R> struct LCM {
-  static constexpr int NG = R <= 3 ? 2 : 1;                  // 4x4-pixel groups per tile
+  static constexpr int NG = R <= 3 ? 2 : 1;                  // 4x4-pixel groups per tile (16x4 tiles for r <= 2: +5 % coherent, -10 % incoherent)
   static constexpr int TP = 16 * NG, TW = 4 * NG, TH = 4;
   static constexpr int WPG = 4 / NG;                         // wavefronts per group
   static constexpr int N2 = 2 * R + 2;
