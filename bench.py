@@ -156,6 +156,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=1, help="image pairs per GPU per step (weak scaling)")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16", "fp32"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / parity leg")
+    ap.add_argument("--no-microbench", action="store_true", help="skip the standalone local_corr launches (for --pmc passes over the pipeline only)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -235,7 +236,7 @@ def main():
             pmc = os.path.join(ROOT, "profiles", "local_corr_traffic.json")
             if os.path.exists(pmc):          # HBM bytes per launch from a separate rocprofv3 --pmc pass (see profiles/README.md)
                 roof["traffic"] = json.load(open(pmc)).get("hbm_bytes_per_launch")
-        micro = local_corr_microbench(device, dtype, P)
+        micro = None if args.no_microbench else local_corr_microbench(device, dtype, P)
         cpu = parity = None
         if do_cpu:
             # parity gate + CPU baseline on a real photograph pair when the fixture images are present (the decoder's

@@ -117,8 +117,12 @@ class ConvRefiner(nn.Module):
         self._prep = (key, prep)
         return prep
 
+    def new_buffer(self, B, h, w, dtype, device):
+        """The channels-last (B,h,w,Dp) concat buffer of one forward; the caller may fill channels [0, C) with x itself."""
+        return torch.empty((B, h, w, self.prepare(dtype)["Dp"]), dtype=dtype, device=device)
+
     @torch.no_grad()
-    def _body(self, x, y, flow, scale_factor, dtype):
+    def _body(self, x, y, flow, scale_factor, dtype, buf=None):
         """Everything up to (not including) out_conv: returns the last block's activation (B,h,w,Dp) and the prepared weights."""
         P = self.prepare(dtype)
         B, C, h, w = x.shape
@@ -127,9 +131,15 @@ class ConvRefiner(nn.Module):
         r = self.local_corr_radius
         K = (2 * r + 1) ** 2 if r else 0
         assert 2 * C + E + K == D, "feature width does not match this refiner"
-        buf = torch.empty((B, h, w, Dp), dtype=dtype, device=x.device)
+        x_in_place = buf is not None
+        if buf is None:
+            buf = torch.empty((B, h, w, Dp), dtype=dtype, device=x.device)
+        assert buf.shape == (B, h, w, Dp) and buf.dtype == dtype and buf.is_contiguous()
         d = buf.permute(0, 3, 1, 2)
-        d[:, :C].copy_(x)
+        if x_in_place:
+            assert x.data_ptr() == buf.data_ptr() and x.stride(1) == 1, "x must already be channels [0, C) of buf"
+        else:
+            d[:, :C].copy_(x)
         if Dp > D:
             buf[..., D:].zero_()
         yy = y.to(dtype)
@@ -163,10 +173,10 @@ class ConvRefiner(nn.Module):
         return out[:, :-1], out[:, -1:]
 
     @torch.no_grad()
-    def forward_update(self, x, y, flow, certainty, scale_factor, sx, sy, dtype=None):
+    def forward_update(self, x, y, flow, certainty, scale_factor, sx, sy, dtype=None, buf=None):
         """The Decoder's use of the refiner (matcher.py:393-402) with out_conv fused into the update kernel:
         flow (B,2,h,w) fp32 contiguous is updated IN PLACE by (sx*dx, sy*dy); returns (flow, certainty + dcert)."""
-        cur, P = self._body(x, y, flow, scale_factor, dtype or self.amp_dtype)
+        cur, P = self._body(x, y, flow, scale_factor, dtype or self.amp_dtype, buf=buf)
         return ops.refiner_head(cur, P["wo"], P["bo"], flow, certainty, sx, sy)
 
 
@@ -271,12 +281,18 @@ class Decoder(nn.Module):
         self._proj = (key, out)
         return out
 
-    def project(self, s, f, dtype):
-        """1x1 conv + BN(eval) as one GEMM over the channels-last rows — matcher.py:366-371."""
+    def project(self, s, f, dtype, out=None):
+        """1x1 conv + BN(eval) as one batched GEMM — matcher.py:366-371.  The NCHW feature map is the GEMM's transposed
+        operand (no layout copy) and the result lands channels-last, directly in `out` when given (a (B,h,w,C) slice of the
+        refiner's concat buffer).  Returns the (B,C,h,w) channels-last view."""
         wt, b = self.folded_proj(dtype)[s]
         B, C, h, w = f.shape
-        rows = f.to(dtype).permute(0, 2, 3, 1).reshape(B * h * w, C)
-        return torch.addmm(b, rows, wt).view(B, h, w, -1).permute(0, 3, 1, 2)
+        a = f.to(dtype).flatten(2).transpose(1, 2)                                            # (B, hw, Cin) view
+        n = wt.shape[1]
+        if out is None:
+            out = torch.empty((B, h, w, n), dtype=dtype, device=f.device)
+        torch.baddbmm(b, a, wt.unsqueeze(0).expand(B, -1, -1), out=out.view(B, h * w, n))
+        return out.permute(0, 3, 1, 2)
 
     @torch.no_grad()
     def forward(self, f1, f2, gt_warp=None, gt_prob=None, upsample=False, flow=None, certainty=None, scale_factor=1,
@@ -300,12 +316,14 @@ class Decoder(nn.Module):
         for s in all_scales:
             ins = int(s)
             corresps[ins] = {}
-            x = self.project(s, f1[ins], dtype)
+            hs, ws = sizes[ins]
+            refiner = self.conv_refiner[s]
+            buf = refiner.new_buffer(b, hs, ws, dtype, device)                               # x lands in its first channels
+            x = self.project(s, f1[ins], dtype, out=buf[..., :self.proj[s][0].out_channels])
             if swapped_pair:
                 y = torch.cat((x[b // 2:], x[:b // 2]), dim=0)
             else:
                 y = self.project(s, f2[ins], dtype)
-            hs, ws = sizes[ins]
             if ins in self.embedding_decoder.scales():
                 xs = x.permute(0, 2, 3, 1).reshape(b, hs * ws, -1)
                 ys = y.permute(0, 2, 3, 1).reshape(b, hs * ws, -1)
@@ -317,8 +335,8 @@ class Decoder(nn.Module):
                 with torch.autocast("cuda", enabled=dtype != torch.float32, dtype=dtype if dtype != torch.float32 else None):
                     rows = self.embedding_decoder.forward_rows(tokens)                        # (b, hw, 4097)
                 flow, certainty = ops.cls_rows_to_flow(rows, b, hs, ws)                       # :378-385
-            flow, certainty = self.conv_refiner[s].forward_update(                             # :393-402
-                x, y, flow, certainty, scale_factor, ins / (self.refine_init * w), ins / (self.refine_init * h), dtype=dtype)
+            flow, certainty = refiner.forward_update(                                         # :393-402
+                x, y, flow, certainty, scale_factor, ins / (self.refine_init * w), ins / (self.refine_init * h), dtype=dtype, buf=buf)
             corresps[ins].update({"certainty": certainty, "flow": flow})
             if s != "1":
                 flow = ops.interp_bilinear(flow, sizes[ins // 2])                             # :408-417
