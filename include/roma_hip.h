@@ -102,6 +102,10 @@ int roma_match_finalize(const float* flow, const float* cert, const float* cert1
  * rounded to fp16 values by the caller when half=True), ref points every `down`-th row.  density (N) fp32. */
 int roma_kde_density(const float* x, float* density, int N, int down, float std, void* stream);
 
+/* VGG19-BN layer epilogue with BatchNorm folded into the convolution — encoders.py:68-78 (conv -> BN -> ReLU):
+ *   x[b,c,:] = max(x[b,c,:] + bias[c], 0) in place on a planar (B,C,HW) map of `dtype`; bias (C) of `dtype`.  B*C <= 65535. */
+int roma_bias_relu_nchw(void* x, const void* bias, int B, int C, int HW, int dtype, void* stream);
+
 /* ConvRefiner block front half — matcher.py:77-103 (create_block: depthwise 5x5 conv, BatchNorm(eval), ReLU),
  * fused, channels-last.  BN is folded by the caller: y = relu(dwconv(x, w) * scale + shift).
  *   x,y: (B,H,W,pitch) `dtype`; w: (25, C) fp32 tap-major; scale, shift: (C) fp32. */

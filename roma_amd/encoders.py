@@ -9,6 +9,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import ops
+
 from .transformer import DinoViT
 
 VGG19_CFG = [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M"]
@@ -69,7 +71,7 @@ class VGG19(nn.Module):
                 scale *= 2
                 x = F.max_pool2d(x, 2, 2)
             else:
-                x = F.relu_(F.conv2d(x, step[0], step[1], padding=1))
+                x = ops.bias_relu_(F.conv2d(x, step[0], None, padding=1), step[1])     # one epilogue pass instead of add_ + relu_
         return feats
 
 

@@ -336,6 +336,19 @@ def dwconv5x5_bn_relu(x, w25, scale, shift, out=None):
     return out
 
 
+def bias_relu_(x, bias):
+    """In place max(x + bias[c], 0) on a contiguous planar (B,C,H,W) map — the folded conv+BN+ReLU epilogue of VGG19-BN
+    (encoders.py:68-78)."""
+    _need_gpu(x, bias)
+    B, C, H, W = x.shape
+    assert x.is_contiguous() and bias.dtype == x.dtype and bias.numel() == C and bias.is_contiguous()
+    step = max(1, 65535 // C)
+    for b0 in range(0, B, step):
+        xb = x[b0:b0 + step]
+        check(_lib.load().roma_bias_relu_nchw(_p(xb), _p(bias), xb.shape[0], C, H * W, _dt(x), _stream()), "roma_bias_relu_nchw")
+    return x
+
+
 def refiner_block(x_nhwc, w25, scale, shift, wt, bias, C, out=None):
     """One fused ConvRefiner block (depthwise 5x5 + BN + ReLU + 1x1 conv, matcher.py:77-103) for C <= 160, fp16/bf16.
     x_nhwc: (B,h,w,pitch) contiguous; w25 (25,kpad), wt (kpad,kpad) [out][in] in x's dtype; scale/shift/bias (kpad) fp32."""

@@ -391,3 +391,13 @@ def test_refiner_block_vs_torch(dtype, C, kpad, B, H, W):
     tol = 4e-3 if dtype == torch.float16 else 3e-2
     err = (out.float() - ref).abs().max().item()
     assert err < tol * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 64, 56, 40), (1, 512, 70, 70), (3, 5, 7, 9)])
+def test_bias_relu_inplace(shape, dtype):
+    x = H.T(R.normal(f"br.{shape}", shape), DEV).to(dtype)
+    b = H.T(R.normal(f"br.b.{shape}", (shape[1],)), DEV).to(dtype)
+    ref = torch.relu(x.float() + b.float().view(1, -1, 1, 1)).to(dtype)
+    out = _ops().bias_relu_(x.clone(), b)
+    assert torch.equal(out, ref)
