@@ -122,6 +122,12 @@ int roma_refiner_block(const void* x, const void* w25, const float* scale, const
                        const float* bias, void* y, int B, int C, int H, int W, int kpad, int dtype, int x_pitch, int y_pitch,
                        void* stream);
 
+/* ConvRefiner block back half at mid widths — matcher.py:102 (Conv2d(D, D, 1)) for 32 < D <= 160, fp16 / bf16, on the
+ * matrix cores:  y[m][n] = bias[n] + sum_k x[m][k] * wt[n][k];  x, y: (M, pitch) channels-last rows (C used, may alias
+ * only if identical); wt: (kpad, kpad) `dtype`, the Conv2d weight itself ([out][in]) zero-padded; bias (kpad) fp32. */
+int roma_pointwise_mfma(const void* x, const void* wt, const float* bias, void* y, long M, int C, int kpad, int dtype,
+                        int x_pitch, int y_pitch, void* stream);
+
 /* ConvRefiner head + Decoder update fused — matcher.py:141 (out_conv, D -> 3, fp32 on d.float()) and :397-402:
  *   d = bo + x[m,:] @ wo;  flow[b,0] += sx*d0;  flow[b,1] += sy*d1;  cert_out = (cert_in ? cert_in : 0) + d2
  *   x: (B*H*W, pitch) channels-last rows of `dtype` (C channels used), wo (C,3) fp32 row-major, bo (3) fp32,

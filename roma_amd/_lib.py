@@ -30,6 +30,7 @@ SIGNATURES = {
     "roma_kde_density": [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
     "roma_dwconv5x5_bn_relu": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "roma_bias_relu_nchw": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "roma_pointwise_mfma": [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "roma_refiner_block": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                            c_int, c_int, c_void_p],
     "roma_refiner_head": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,

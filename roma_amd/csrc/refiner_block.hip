@@ -207,6 +207,88 @@ int launch_rb(const RBParams& p, hipStream_t s) {
   ROMA_CHECK_LAUNCH();
 }
 
+
+// ---- 1x1 convolution alone at mid widths (32 < C <= 160), for the refiner whose depthwise half stays a separate kernel:
+// y[m][n] = bias[n] + sum_k x[m][k] * wt[n][k].  hipBLASLt runs this skinny GEMM (N = K = 144, M = 10^5..10^6) at ~2 TB/s of
+// in+out; here it is a streaming kernel: the weights sit in LDS once per (persistent) workgroup, every wavefront takes 16
+// rows at a time, its A fragments are the 16-byte channel packets straight from global memory, the products go
+// through a wave-private LDS patch for 16-byte stores.  No workgroup barrier after the weight load. ----
+struct PWParams {
+  const void* x;
+  void* y;
+  const void* wt;     // (kpad, kpad) T: wt[n][k], zero-padded
+  const float* bias;  // (kpad)
+  long M;
+  int C, x_pitch, y_pitch;
+};
+
+template <typename T, int KP>
+__global__ __launch_bounds__(256, 2) void pointwise_mfma_kernel(PWParams p) {
+  constexpr int KPAD = 32 * KP, NT = KPAD / 16, RS = KPAD / 8 + 1, OS = KPAD + 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u32x4* s_pw = reinterpret_cast<u32x4*>(smem);                         // [KPAD][RS]
+  float* s_b = reinterpret_cast<float*>(s_pw + KPAD * RS);              // [KPAD]
+  T* s_out = reinterpret_cast<T*>(s_b + KPAD);                          // [4 waves][16][OS]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int m = lane & 15, kq = lane >> 4;
+  const int PKT = p.C / 8;
+  for (int i = tid; i < KPAD * (KPAD / 8); i += 256) {
+    const int n = i / (KPAD / 8), k = i % (KPAD / 8);
+    s_pw[n * RS + k] = reinterpret_cast<const u32x4*>(p.wt)[i];
+  }
+  for (int i = tid; i < KPAD; i += 256) s_b[i] = p.bias[i];
+  __syncthreads();
+  const T* x = static_cast<const T*>(p.x);
+  T* y = static_cast<T*>(p.y);
+  T* so = s_out + wv * 16 * OS;
+  const long ntile = (p.M + 15) / 16;
+  for (long tile = (long)blockIdx.x * 4 + wv; tile < ntile; tile += (long)gridDim.x * 4) {
+    const long row0 = tile * 16;
+    const long r = row0 + m < p.M ? row0 + m : p.M - 1;
+    u32x4 a[KP];
+#pragma unroll
+    for (int ks = 0; ks < KP; ++ks) {
+      const int pk = 4 * ks + kq;
+      u32x4 v = *reinterpret_cast<const u32x4*>(x + r * p.x_pitch + (pk < PKT ? pk : 0) * 8);
+      if (pk >= PKT) v = u32x4{0, 0, 0, 0};
+      a[ks] = v;
+    }
+    float4_t acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      acc[nt] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KP; ++ks) acc[nt] = mfma_blk(a[ks], s_pw[(nt * 16 + m) * RS + 4 * ks + kq], acc[nt], T{});
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const float bv = s_b[nt * 16 + m];
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) so[(4 * kq + r4) * OS + nt * 16 + m] = from_f32<T>(acc[nt][r4] + bv);
+    }
+    for (int i = lane; i < 16 * PKT; i += 64) {
+      const int row = i / PKT, k = i - row * PKT;
+      if (row0 + row < p.M) *reinterpret_cast<u32x4*>(y + (row0 + row) * p.y_pitch + k * 8) = *reinterpret_cast<const u32x4*>(so + row * OS + k * 8);
+    }
+  }
+}
+
+template <typename T, int KP>
+int launch_pw(const PWParams& p, hipStream_t s) {
+  constexpr int KPAD = 32 * KP, RS = KPAD / 8 + 1, OS = KPAD + 8;
+  const size_t smem = (size_t)KPAD * RS * 16 + KPAD * 4 + (size_t)4 * 16 * OS * sizeof(T);
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pointwise_mfma_kernel<T, KP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) { set_error("roma_pointwise_mfma: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    attr_done = true;
+  }
+  const long need = (p.M + 63) / 64;
+  const int grid = (int)(need < 512 ? need : 512);             // two persistent workgroups per CU
+  hipLaunchKernelGGL((pointwise_mfma_kernel<T, KP>), dim3(grid), dim3(256), smem, s, p);
+  ROMA_CHECK_LAUNCH();
+}
+
 }  // namespace
 }  // namespace roma
 
@@ -225,4 +307,18 @@ extern "C" int roma_refiner_block(const void* x, const void* w25, const float* s
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype == ROMA_F16) return kpad == 32 ? launch_rb<half_t, 1>(p, s) : launch_rb<half_t, 5>(p, s);
   return kpad == 32 ? launch_rb<bf16_t, 1>(p, s) : launch_rb<bf16_t, 5>(p, s);
+}
+
+extern "C" int roma_pointwise_mfma(const void* x, const void* wt, const float* bias, void* y, long M, int C, int kpad, int dtype,
+                                   int x_pitch, int y_pitch, void* stream) {
+  ROMA_REQUIRE(x && wt && bias && y, ROMA_E_ARG, "roma_pointwise_mfma: null pointer");
+  ROMA_REQUIRE(M > 0 && C > 0 && x_pitch >= C && y_pitch >= C, ROMA_E_SHAPE, "roma_pointwise_mfma: bad shape");
+  ROMA_REQUIRE(dtype == ROMA_F16 || dtype == ROMA_BF16, ROMA_E_DTYPE, "roma_pointwise_mfma: fp16 / bf16 only");
+  ROMA_REQUIRE((kpad == 32 || kpad == 160) && C <= kpad && C % 8 == 0, ROMA_E_UNSUPPORTED, "roma_pointwise_mfma: C=%d, kpad=%d", C, kpad);
+  ROMA_REQUIRE(x_pitch % 8 == 0 && y_pitch % 8 == 0 && aligned16(x) && aligned16(y) && aligned16(wt), ROMA_E_ALIGN,
+               "roma_pointwise_mfma: pitches must be multiples of 8 and bases 16-byte aligned");
+  PWParams p{x, y, wt, bias, M, C, x_pitch, y_pitch};
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == ROMA_F16) return kpad == 32 ? launch_pw<half_t, 1>(p, s) : launch_pw<half_t, 5>(p, s);
+  return kpad == 32 ? launch_pw<bf16_t, 1>(p, s) : launch_pw<bf16_t, 5>(p, s);
 }

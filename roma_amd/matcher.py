@@ -85,6 +85,7 @@ class ConvRefiner(nn.Module):
         # (LDS-read and VALU bound there) -> narrow refiners only unless ROMA_FUSED_BLOCK=160
         fuse_max = int(os.environ.get("ROMA_FUSED_BLOCK", "32"))
         fused = Dp <= min(fuse_max, 160) and dtype in (torch.float16, torch.bfloat16)
+        mid = (not fused) and 32 < Dp <= 160 and dtype in (torch.float16, torch.bfloat16) and os.environ.get("ROMA_PW_MFMA", "1") != "0"
         blocks = []
         for blk in [self.block1] + list(self.hidden_blocks):
             dw, bn, _, pw = blk
@@ -105,6 +106,9 @@ class ConvRefiner(nn.Module):
                 kp = 32 if Dp <= 32 else 160
                 blocks.append((_zero_pad(w25, 25, kp).to(dtype), _zero_pad(scale, kp), _zero_pad(shift, kp),
                                _zero_pad(wt.t(), kp, kp).to(dtype), _zero_pad(b, kp)))
+            elif mid:
+                # mid widths (D = 144): depthwise kernel + streaming MFMA 1x1 (ops.pointwise_mfma), weight [out][in] padded to 160
+                blocks.append((w25.contiguous(), scale, shift, _zero_pad(wt.t(), 160, 160).to(dtype), _zero_pad(b, 160)))
             # narrow refiners (Dp <= 32): the 1x1 conv is a streaming op -> own kernel with fp32 weights; else a library GEMM
             elif Dp <= 32:
                 blocks.append((w25.contiguous(), scale, shift, wt.contiguous(), b.contiguous()))
@@ -112,7 +116,7 @@ class ConvRefiner(nn.Module):
                 blocks.append((w25.contiguous(), scale, shift, wt.to(dtype).contiguous(), b.to(dtype)))
         wo = torch.zeros(Dp, self.out_dim, device=dev)
         wo[:D] = self.out_conv.weight.float().reshape(self.out_dim, D).t()
-        prep = dict(D=D, Dp=Dp, fused=fused, blocks=blocks, wo=wo.contiguous(), bo=self.out_conv.bias.float(),
+        prep = dict(D=D, Dp=Dp, fused=fused, mid=mid, blocks=blocks, wo=wo.contiguous(), bo=self.out_conv.bias.float(),
                     we=self.disp_emb.weight.float().reshape(-1, 2).contiguous(), be=self.disp_emb.bias.float())
         self._prep = (key, prep)
         return prep
@@ -158,7 +162,11 @@ class ConvRefiner(nn.Module):
         for (w25, scale, shift, wt, b) in P["blocks"]:                                         # :139-140
             t = ops.dwconv5x5_bn_relu(cur.permute(0, 3, 1, 2), w25, scale, shift)
             rows = t.permute(0, 2, 3, 1).reshape(M, Dp)
-            cur = (ops.pointwise_small(rows, wt, b) if Dp <= 32 else torch.addmm(b, rows, wt)).view(B, h, w, Dp)
+            if P["mid"]:
+                cur = ops.pointwise_mfma(rows, wt, b, Dp)
+            else:
+                cur = ops.pointwise_small(rows, wt, b) if Dp <= 32 else torch.addmm(b, rows, wt)
+            cur = cur.view(B, h, w, Dp)
         return cur, P
 
     @torch.no_grad()

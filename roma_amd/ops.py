@@ -349,6 +349,21 @@ def bias_relu_(x, bias):
     return x
 
 
+def pointwise_mfma(rows, wt, bias, C, out=None):
+    """rows (M, pitch) @ wt[:C,:C]^T + bias for 32 < C <= 160 on the matrix cores (matcher.py:102).  wt (kpad,kpad) [out][in] in
+    rows' dtype, bias (kpad) fp32; out may be `rows` itself only for a full in-place update of the same rows."""
+    _need_gpu(rows, wt, bias, out)
+    M, pitch = rows.shape
+    kpad = wt.shape[0]
+    assert rows.is_contiguous() and wt.is_contiguous() and wt.dtype == rows.dtype and bias.numel() == kpad and bias.dtype == torch.float32
+    if out is None:
+        out = torch.empty_like(rows)
+    assert out.shape == rows.shape and out.is_contiguous()
+    check(_lib.load().roma_pointwise_mfma(_p(rows), _p(wt), _p(bias), _p(out), M, C, kpad, _dt(rows), pitch, pitch, _stream()),
+          "roma_pointwise_mfma")
+    return out
+
+
 def refiner_block(x_nhwc, w25, scale, shift, wt, bias, C, out=None):
     """One fused ConvRefiner block (depthwise 5x5 + BN + ReLU + 1x1 conv, matcher.py:77-103) for C <= 160, fp16/bf16.
     x_nhwc: (B,h,w,pitch) contiguous; w25 (25,kpad), wt (kpad,kpad) [out][in] in x's dtype; scale/shift/bias (kpad) fp32."""

@@ -58,9 +58,14 @@ class Block(nn.Module):
         self.mlp = Mlp(dim, int(dim * 4.0))
         self.ls2 = LayerScale(dim, init_values) if init_values else nn.Identity()
 
+    @staticmethod
+    def _residual(x, y, ls):
+        # x + gamma * y in one elementwise pass (the reference's LayerScale + residual are two, layers/block.py:87-107)
+        return torch.addcmul(x, y, ls.gamma.to(y.dtype)) if isinstance(ls, LayerScale) else x + y
+
     def forward(self, x):
-        x = x + self.ls1(self.attn(self.norm1(x)))
-        return x + self.ls2(self.mlp(self.norm2(x)))
+        x = self._residual(x, self.attn(self.norm1(x)), self.ls1)
+        return self._residual(x, self.mlp(self.norm2(x)), self.ls2)
 
 
 class TransformerDecoder(nn.Module):

@@ -401,3 +401,20 @@ def test_bias_relu_inplace(shape, dtype):
     ref = torch.relu(x.float() + b.float().view(1, -1, 1, 1)).to(dtype)
     out = _ops().bias_relu_(x.clone(), b)
     assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("C,kpad,M", [(144, 160, 4999), (144, 160, 64), (160, 160, 1000), (48, 160, 333), (24, 32, 777)])
+def test_pointwise_mfma_vs_torch(C, kpad, M, dtype):
+    """Streaming MFMA 1x1 conv (matcher.py:102) vs an fp32 matmul on the same rounded operands."""
+    g = torch.Generator().manual_seed(C + M)
+    x = torch.randn(M, C, generator=g).to(DEV).to(dtype)
+    wt = torch.zeros(kpad, kpad)
+    wt[:C, :C] = torch.randn(C, C, generator=g) / C ** 0.5
+    bias = torch.zeros(kpad)
+    bias[:C] = torch.randn(C, generator=g) * 0.1
+    wtd = wt.to(DEV).to(dtype)
+    out = _ops().pointwise_mfma(x, wtd, bias.to(DEV), C)
+    ref = x.float() @ wtd.float()[:C, :C].t() + bias[:C].to(DEV)
+    tol = (2 ** -10 if dtype == torch.float16 else 2 ** -7) * max(1.0, float(ref.abs().max()))
+    assert maxerr(out, ref) <= tol
