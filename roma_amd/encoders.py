@@ -62,8 +62,8 @@ class VGG19(nn.Module):
     def forward(self, x, dtype=torch.float16):
         feats, scale = {}, 1
         # planar (NCHW) activations: MIOpen's fp16 3x3 solvers measure 18 % faster than its channels-last ones on
-        # gfx950 for this stack (5.7 vs 7.0 ms for the 560 + 864 passes); the captured maps are re-laid out
-        # channels-last by the decoder's projection (one pass over each)
+        # gfx950 for this stack (5.7 vs 7.0 ms for the 560 + 864 passes); the decoder's projection GEMM
+        # reads the planar maps as its transposed operand and writes channels-last, so no layout pass is needed
         x = x.to(dtype).contiguous()
         for step in self.fold(dtype):
             if step is None:

@@ -52,9 +52,11 @@ def _zero_pad(t, *shape):
 
 
 class ConvRefiner(nn.Module):
-    """x, warped y, displacement embedding and local correlation are assembled in ONE channels-last buffer
-    (pitch padded to 8 channels) by four kernels writing channel slices; every block is the fused
-    depthwise5x5+BN+ReLU kernel followed by a hipBLASLt GEMM for the 1x1 convolution."""
+    """x, warped y, displacement embedding and local correlation are assembled in ONE channels-last buffer (pitch padded to
+    8 channels): the decoder's projection GEMM writes x there, three kernels write the other channel slices.  A block
+    (depthwise 5x5 + BN + ReLU + 1x1) is, by width: D <= 32 one fused kernel (ops.refiner_block); 32 < D <= 160 the
+    depthwise kernel + the streaming MFMA 1x1 (ops.pointwise_mfma); wider, the depthwise kernel + a hipBLASLt GEMM.  fp32
+    (parity mode) always takes the separate kernels."""
 
     def __init__(self, in_dim, hidden_dim, out_dim, hidden_blocks, displacement_emb_dim, local_corr_radius=None,
                  amp_dtype=torch.float16):
