@@ -102,6 +102,16 @@ int roma_match_finalize(const float* flow, const float* cert, const float* cert1
  * rounded to fp16 values by the caller when half=True), ref points every `down`-th row.  density (N) fp32. */
 int roma_kde_density(const float* x, float* density, int N, int down, float std, void* stream);
 
+/* Pre-processing on the device — utils.py:165-261 (TupleResize = PIL bicubic, ToTensorScaled, TupleNormalize), bit-identical
+ * to the host path.  One pass of PIL's 8-bit resampling (Pillow Resample.c): out = clip8((2^21 + sum_k in[lo+k] * coef[k]) >> 22).
+ *   in: uint8 (H, W, C);  axis 1: out (H, out_size, C), axis 0: out (out_size, W, C);
+ *   bounds: int32 (out_size, 2) = (first input index, tap count); coef: int32 (out_size, ksize) 22-bit fixed point
+ *   (computed on the host like precompute_coeffs / normalize_coeffs_8bpc: roma_amd/preproc.py). */
+int roma_resample_u8(const void* in, void* out, int H, int W, int C, int out_size, int axis, const int* bounds,
+                     const int* coef, int ksize, void* stream);
+/*   uint8 (H, W, 3) -> fp32 (3, H, W): ((v / 255) - mean[c]) / std[c];  mean3, std3 are HOST pointers to 3 floats. */
+int roma_normalize_u8(const void* in, float* out, int H, int W, const float* mean3, const float* std3, void* stream);
+
 /* VGG19-BN layer epilogue with BatchNorm folded into the convolution — encoders.py:68-78 (conv -> BN -> ReLU):
  *   x[b,c,:] = max(x[b,c,:] + bias[c], 0) in place on a planar (B,C,HW) map of `dtype`; bias (C) of `dtype`.  B*C <= 65535. */
 int roma_bias_relu_nchw(void* x, const void* bias, int B, int C, int HW, int dtype, void* stream);

@@ -29,6 +29,8 @@ SIGNATURES = {
     "roma_match_finalize": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "roma_kde_density": [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
     "roma_dwconv5x5_bn_relu": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "roma_resample_u8": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p],
+    "roma_normalize_u8": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "roma_bias_relu_nchw": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "roma_pointwise_mfma": [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "roma_refiner_block": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -389,6 +389,7 @@ class RegressionMatcher(nn.Module):
         self.upsample_res = (14 * 16 * 6, 14 * 16 * 6)
         self.symmetric = symmetric
         self.sample_thresh = 0.05
+        self.host_preprocess = False          # True: PIL resize on the host like the reference (same bits, slower)
 
     def get_output_resolution(self):
         return self.upsample_res if self.upsample_preds else (self.h_resized, self.w_resized)
@@ -527,8 +528,16 @@ class RegressionMatcher(nn.Module):
             else:
                 _check_rgb(im)
             ims.append(im)
-        lo = [preprocess(im, (self.h_resized, self.w_resized))[None].to(device) for im in ims]
-        hi = [preprocess(im, self.upsample_res)[None].to(device) for im in ims] if self.upsample_preds else [None, None]
+        if getattr(self, "host_preprocess", False):
+            # the reference's way: PIL resizes each image once per resolution on the host, fp32 tensors cross PCIe
+            lo = [preprocess(im, (self.h_resized, self.w_resized))[None].to(device) for im in ims]
+            hi = [preprocess(im, self.upsample_res)[None].to(device) for im in ims] if self.upsample_preds else [None, None]
+        else:
+            # one uint8 upload per photograph; both resolutions are resized + normalised on the device, bit-identical to PIL
+            from .preproc import preprocess_device
+            src = [torch.from_numpy(np.array(im, dtype=np.uint8)).to(device) for im in ims]
+            lo = [preprocess_device(s, (self.h_resized, self.w_resized), device)[None] for s in src]
+            hi = [preprocess_device(s, self.upsample_res, device)[None] for s in src] if self.upsample_preds else [None, None]
         warp, cert = self.match_tensors(lo[0], lo[1], hi[0], hi[1])
         return warp[0], cert[0]
 

@@ -336,6 +336,31 @@ def dwconv5x5_bn_relu(x, w25, scale, shift, out=None):
     return out
 
 
+def resample_u8(img, out_size, axis, bounds, coef, ksize):
+    """One pass of PIL's 8-bit resampling (see roma_amd/preproc.py): img uint8 (H,W,C) CUDA, axis 1 = horizontal."""
+    _need_gpu(img, bounds, coef)
+    H, W, C = img.shape
+    assert img.dtype == torch.uint8 and img.is_contiguous() and bounds.dtype == torch.int32 and coef.dtype == torch.int32
+    assert bounds.shape == (out_size, 2) and coef.shape == (out_size, ksize) and bounds.is_contiguous() and coef.is_contiguous()
+    out = torch.empty((H, out_size, C) if axis else (out_size, W, C), dtype=torch.uint8, device=img.device)
+    check(_lib.load().roma_resample_u8(_p(img), _p(out), H, W, C, out_size, axis, _p(bounds), _p(coef), ksize, _stream()), "roma_resample_u8")
+    return out
+
+
+def normalize_u8(img, mean, std):
+    """uint8 (H,W,3) CUDA -> fp32 (3,H,W): ((v/255) - mean)/std, the reference's operation order (utils.py:176-185, 251-261)."""
+    import ctypes
+    _need_gpu(img)
+    H, W, C = img.shape
+    assert C == 3 and img.dtype == torch.uint8 and img.is_contiguous()
+    out = torch.empty((3, H, W), dtype=torch.float32, device=img.device)
+    m = (ctypes.c_float * 3)(*mean)
+    s = (ctypes.c_float * 3)(*std)
+    check(_lib.load().roma_normalize_u8(_p(img), _p(out), H, W, ctypes.cast(m, ctypes.c_void_p), ctypes.cast(s, ctypes.c_void_p), _stream()),
+          "roma_normalize_u8")
+    return out
+
+
 def bias_relu_(x, bias):
     """In place max(x + bias[c], 0) on a contiguous planar (B,C,H,W) map — the folded conv+BN+ReLU epilogue of VGG19-BN
     (encoders.py:68-78)."""

@@ -255,3 +255,21 @@ def test_tiny_roma_forward_and_match_golden():
         assert maxerr(c[s]["certainty"], H.T(g[f"fwd_cert_{s}"])) < 2e-4
     warp, cert = m.match(im0, im1)
     assert maxerr(warp, H.T(g["match_warp"])) < 2e-4 and maxerr(cert, H.T(g["match_cert"])) < 2e-4
+
+
+def test_device_preprocessing_is_bit_identical_to_pil():
+    """PIL bicubic resize + /255 + normalise (utils.py:165-261) done on the device from one uint8 upload
+    must equal the host path bit for bit — so match() from files is unchanged by it."""
+    import os
+    from PIL import Image
+    from roma_amd.matcher import preprocess
+    from roma_amd.preproc import preprocess_device, resize_device
+    root = os.path.join(os.path.dirname(__file__), "golden", "assets")
+    for name in ("sacre_coeur_A.jpg", "sacre_coeur_B.jpg"):
+        im = Image.open(os.path.join(root, name)).convert("RGB")
+        for size in [(560, 560), (864, 864), (37, 53), (1000, 700)]:
+            dev = preprocess_device(im, size, DEV)
+            host = preprocess(im, size)
+            assert dev.shape == host.shape and torch.equal(dev.cpu(), host), (name, size)
+        u8 = resize_device(torch.from_numpy(np.array(im, dtype=np.uint8)).to(DEV), (123, 77)).cpu().numpy()
+        assert np.array_equal(u8, np.asarray(im.resize((77, 123), Image.BICUBIC)))

@@ -129,3 +129,23 @@ def test_shard_ranges_cover_all_pairs_in_order():
             assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
     with pytest.raises(ValueError):
         shard_range(4, 2, 2)
+
+
+def test_pil_bicubic_integer_restatement_is_bit_exact():
+    """roma_amd/preproc.py: the fixed-point tables + two integer passes reproduce PIL.Image.resize(BICUBIC) bit for bit
+    (down-scaling with antialias support, up-scaling, non-square, one axis untouched) — the reference's TupleResize,
+    utils.py:234-239.  This is the host-side reference of the roma_resample_u8 kernel."""
+    import os
+    import numpy as np
+    from PIL import Image
+    from roma_amd.preproc import resample_numpy, resample_tables
+    root = os.path.join(os.path.dirname(__file__), "golden", "assets")
+    for name in ("sacre_coeur_A.jpg", "sacre_coeur_B.jpg"):
+        im = Image.open(os.path.join(root, name)).convert("RGB")
+        a = np.asarray(im)
+        for size in [(560, 560), (864, 864), (37, 53), (a.shape[0] * 2, a.shape[1] + 7), (a.shape[0], 300)]:
+            ref = np.asarray(im.resize((size[1], size[0]), Image.BICUBIC))
+            assert np.array_equal(resample_numpy(a, size), ref), (name, size)
+    b, k, ks = resample_tables(640, 560)
+    assert b.shape == (560, 2) and k.shape == (560, ks) and ks == 7
+    assert (np.abs(k.sum(axis=1) - (1 << 22)) <= ks).all()          # every row of 22-bit fixed-point weights sums to 1
