@@ -104,10 +104,15 @@ class CNNandDinov2(nn.Module):
         return hit
 
     @torch.no_grad()
-    def forward(self, x, upsample=False):
+    def vit_features(self, x):
+        """DINOv2 patch tokens as a (B,1024,H/14,W/14) channels-last view (encoders.py:114-121)."""
         B, C, H, W = x.shape
+        t = self._vit(x.device).patch_tokens(x.to(self.amp_dtype))
+        return t.reshape(B, H // 14, W // 14, -1).permute(0, 3, 1, 2)
+
+    @torch.no_grad()
+    def forward(self, x, upsample=False):
         pyr = self.cnn(x, self.amp_dtype)
         if not upsample:                                                      # encoders.py:114
-            t = self._vit(x.device).patch_tokens(x.to(self.amp_dtype))
-            pyr[16] = t.reshape(B, H // 14, W // 14, -1).permute(0, 3, 1, 2)  # channels-last view of the token rows
+            pyr[16] = self.vit_features(x)
         return pyr

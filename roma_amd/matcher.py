@@ -306,7 +306,7 @@ class Decoder(nn.Module):
 
     @torch.no_grad()
     def forward(self, f1, f2, gt_warp=None, gt_prob=None, upsample=False, flow=None, certainty=None, scale_factor=1,
-                swapped_pair=False):
+                swapped_pair=False, wait_events=None):
         """Coarse-to-fine loop.  `swapped_pair=True` tells the decoder that f2 is f1 with its two batch halves swapped
         (forward_symmetric), so each level is projected once."""
         dtype = self.amp_dtype
@@ -326,6 +326,8 @@ class Decoder(nn.Module):
         for s in all_scales:
             ins = int(s)
             corresps[ins] = {}
+            if wait_events and ins in wait_events:          # features of this level (and below) come from another stream
+                torch.cuda.current_stream().wait_event(wait_events[ins])
             hs, ws = sizes[ins]
             refiner = self.conv_refiner[s]
             buf = refiner.new_buffer(b, hs, ws, dtype, device)                               # x lands in its first channels
@@ -406,12 +408,14 @@ class RegressionMatcher(nn.Module):
             f_s = {s: f.chunk(2)[1] for s, f in pyr.items()}
         else:
             f_q, f_s = pyr
-        return self.decoder(f_q, f_s, upsample=upsample, scale_factor=scale_factor, **(batch.get("corresps") or {}))
+        return self.decoder(f_q, f_s, upsample=upsample, scale_factor=scale_factor, wait_events=batch.get("wait_events"),
+                            **(batch.get("corresps") or {}))
 
     def forward_symmetric(self, batch, batched=True, upsample=False, scale_factor=1):
         pyr = batch.get("pyramid") or self.extract_backbone_features(batch, batched=batched, upsample=upsample)   # matcher.py:516-528
         kw = {k: v for k, v in (batch.get("corresps") or {}).items() if k in ("flow", "certainty")}
-        return self.decoder(pyr, None, upsample=upsample, scale_factor=scale_factor, swapped_pair=True, **kw)
+        return self.decoder(pyr, None, upsample=upsample, scale_factor=scale_factor, swapped_pair=True,
+                            wait_events=batch.get("wait_events"), **kw)
 
     # -- sampling --------------------------------------------------------------------------------
     def sample(self, matches, certainty, num=10000):
@@ -471,18 +475,30 @@ class RegressionMatcher(nn.Module):
         pass.  Returns the stack of per-pair results: warp (P,H,2W,4), certainty (P,H,2W) (symmetric) — the batched
         560->864 semantics the reference leaves undefined (its batched+upsample path raises)."""
         symmetric = self.symmetric
-        # The 864 VGG pyramid does not depend on the coarse pass: once the coarse encoders are queued, run it on a second
-        # HIP stream so that its large convolutions fill the CUs the coarse decoder's small, latency-bound kernels (GP
-        # solve, 40x40 / 70x70 refiners) leave idle.  Joined before the upsample decoder.
+        # Stream plan.  Only the DINOv2 features feed the first decoder stage (GP + transformer + scale-16 refiner), and
+        # that stage is a chain of small, latency-bound kernels.  So the ViT runs first on the main stream, and BOTH VGG
+        # pyramids (560 for the coarse levels 8..1, 864 for the upsample pass) run on a second HIP stream behind it, filling
+        # the CUs the GP solve leaves idle.  The decoder waits for the 560 pyramid before its scale-8 level and for the 864
+        # one before the upsample pass.
         batch = {"im_A": A_lo, "im_B": B_lo}
-        batch["pyramid"] = self.extract_backbone_features(batch, batched=True)
         hi_pyr = None
-        if self.upsample_preds and A_hi is not None and B_hi is not None and getattr(self, "overlap_upsample_encoder", True):
+        overlap = getattr(self, "overlap_upsample_encoder", True) and hasattr(self.encoder, "vit_features")
+        if overlap:
+            x_lo = torch.cat((A_lo, B_lo), dim=0)
+            pyr = {16: self.encoder.vit_features(x_lo)}
             main = torch.cuda.current_stream()
             side = self._side_stream = getattr(self, "_side_stream", None) or torch.cuda.Stream()
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                hi_pyr = self.extract_backbone_features({"im_A": A_hi, "im_B": B_hi}, batched=True, upsample=True)
+                pyr.update(self.encoder.cnn(x_lo, self.encoder.amp_dtype))
+                lo_ready = torch.cuda.Event()
+                lo_ready.record(side)
+                if self.upsample_preds and A_hi is not None and B_hi is not None:
+                    hi_pyr = self.extract_backbone_features({"im_A": A_hi, "im_B": B_hi}, batched=True, upsample=True)
+            batch["pyramid"] = pyr
+            batch["wait_events"] = {8: lo_ready}
+        else:
+            batch["pyramid"] = self.extract_backbone_features(batch, batched=True)
         corresps = self.forward_symmetric(batch) if symmetric else self.forward(batch, batched=True)
         hs, ws = A_lo.shape[-2:]
         cert16 = corresps[16]["certainty"] if self.attenuate_cert else None
