@@ -22,10 +22,13 @@ class Attention(nn.Module):
         self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
         self.proj = nn.Linear(dim, dim)
 
-    def forward(self, x):
+    def forward(self, x, n_valid=None):
+        """n_valid: the first n_valid tokens are real, the rest is row padding (see DinoViT.patch_tokens): every token
+        queries, only real tokens are keys / values, so padding never reaches a real token."""
         B, N, C = x.shape
         qkv = self.qkv(x).view(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4)
-        o = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2])          # scale = head_dim^-0.5, as attention.py:53-56
+        k, v = (qkv[1], qkv[2]) if n_valid is None else (qkv[1][:, :, :n_valid], qkv[2][:, :, :n_valid])
+        o = F.scaled_dot_product_attention(qkv[0], k, v)                      # scale = head_dim^-0.5, as attention.py:53-56
         return self.proj(o.transpose(1, 2).reshape(B, N, C))
 
 
@@ -63,8 +66,8 @@ class Block(nn.Module):
         # x + gamma * y in one elementwise pass (the reference's LayerScale + residual are two, layers/block.py:87-107)
         return torch.addcmul(x, y, ls.gamma.to(y.dtype)) if isinstance(ls, LayerScale) else x + y
 
-    def forward(self, x):
-        x = self._residual(x, self.attn(self.norm1(x)), self.ls1)
+    def forward(self, x, n_valid=None):
+        x = self._residual(x, self.attn(self.norm1(x), n_valid), self.ls1)
         return self._residual(x, self.mlp(self.norm2(x)), self.ls2)
 
 
@@ -136,6 +139,15 @@ class DinoViT(nn.Module):
         B, _, w, h = x.shape
         t = self.patch_embed(x)
         t = torch.cat((self.cls_token.expand(B, -1, -1), t), dim=1) + self.pos_encoding(w, h, t.dtype)
+        n = t.shape[1]
+        n_valid = None
+        if t.dtype != torch.float32 and n % 128:
+            # The flash-attention kernel runs 1.5x faster when the QUERY length is a multiple of its 128-row tile
+            # (1601 tokens: 90 us, 1664: 61 us per layer on MI355X).  The sequence is padded once, here; padded rows are
+            # queries only (keys / values are sliced to the real tokens in every block), so they cannot influence a real
+            # token, and the GEMMs' tile count does not change (3202 -> 3328 rows = 13 tiles of 256 either way).
+            n_valid = n
+            t = F.pad(t, (0, 0, 0, 128 - n % 128))
         for blk in self.blocks:
-            t = blk(t)
-        return self.norm(t)[:, 1:]
+            t = blk(t, n_valid)
+        return self.norm(t[:, 1:n])
