@@ -86,7 +86,15 @@ class TransformerDecoder(nn.Module):
         return self._scales.copy()
 
     def forward_rows(self, tokens):
-        return self.to_out(self.blocks(tokens))
+        n = tokens.shape[1]
+        if tokens.dtype == torch.float32 or n % 128 == 0:
+            return self.to_out(self.blocks(tokens))
+        # 16-bit mode: row-pad the sequence to the attention / GEMM tile (see DinoViT.patch_tokens); padding rows are
+        # queries only and are dropped from the returned view
+        t = F.pad(tokens, (0, 0, 0, 128 - n % 128))
+        for blk in self.blocks:
+            t = blk(t, n)
+        return self.to_out(t)[:, :n]
 
 
 class PatchEmbed(nn.Module):
