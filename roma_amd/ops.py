@@ -252,37 +252,43 @@ def cos_kernel(x, y, T=0.2, eps=1e-6, diag_add=0.0):
 
 
 def spd_solve(K, F, nb=64):
-    """Solve K X = F for a batch of SPD matrices by a hand-blocked Cholesky: K (B,n,n) fp32 (DESTROYED: its lower triangle
-    becomes L), F (B,n,m) fp32.  Diagonal blocks are factored (and their factors inverted) by roma_chol_diag_block; panels,
-    trailing updates and the two substitutions are GEMMs.  Replaces `inv(K) @ F` of GP.forward (matcher.py:259-263)."""
+    """Solve K X = F for a batch of SPD matrices by a hand-blocked Cholesky: K (B,n,n) fp32, F (B,n,m) fp32.  Replaces
+    `inv(K) @ F` of GP.forward (matcher.py:259-263).
+
+    Works on the augmented matrix A = [K | F] kept fully symmetric in its K part.  Per 64-wide block step s:
+      1. roma_chol_diag_block factors the diagonal block and also emits W = L_ss^-1;
+      2. ONE GEMM  R = W @ A[rows of the block, columns right of it] = [L_panel^T | Y_s]  (the transposed Cholesky panel and
+         the block's share of the forward substitution at once);
+      3. ONE GEMM  A[below, right] -= R_left^T @ R  (trailing update of K and of the right-hand sides together).
+    The forward substitution therefore never runs as a separate sweep; the backward one takes two GEMMs per block.
+    125 launches for n = 1600 instead of the 250 of the textbook three-sweep form."""
     _need_gpu(K, F)
-    assert K.dtype == torch.float32 and F.dtype == torch.float32 and K.is_contiguous()
+    assert K.dtype == torch.float32 and F.dtype == torch.float32
     B, n, _ = K.shape
+    m = F.shape[2]
     lib = _lib.load()
+    A = torch.cat((K, F), dim=2)                                  # (B, n, n+m)
     steps = [(j, min(j + nb, n)) for j in range(0, n, nb)]
     W = torch.empty((B, len(steps), nb, nb), dtype=torch.float32, device=K.device)
     info = torch.zeros((B,), dtype=torch.int32, device=K.device)
+    R = []
     for s, (j, e) in enumerate(steps):
         w = e - j
-        Ajj = K[:, j:e, j:e]
-        check(lib.roma_chol_diag_block(Ajj.data_ptr(), K.stride(1), K.stride(0), W[:, s].data_ptr(), nb, W.stride(0), w, B,
+        check(lib.roma_chol_diag_block(A[:, j:e, j:e].data_ptr(), A.stride(1), A.stride(0), W[:, s].data_ptr(), nb, W.stride(0), w, B,
                                        info.data_ptr(), _stream()), "roma_chol_diag_block")
+        r = torch.bmm(W[:, s, :w, :w], A[:, j:e, e:])             # (B, w, (n-e)+m) = [L[e:, j:e]^T | Y[j:e]]
+        R.append(r)
         if e < n:
-            P = torch.bmm(K[:, e:, j:e], W[:, s, :w, :w].transpose(1, 2))
-            K[:, e:, j:e] = P
-            K[:, e:, e:].baddbmm_(P, P.transpose(1, 2), alpha=-1.0)
-    X = F.clone()
-    for s, (j, e) in enumerate(steps):                       # L Y = F
-        w = e - j
-        X[:, j:e] = torch.bmm(W[:, s, :w, :w], X[:, j:e])
-        if e < n:
-            X[:, e:].baddbmm_(K[:, e:, j:e], X[:, j:e], alpha=-1.0)
-    for s in range(len(steps) - 1, -1, -1):                  # L^T X = Y
+            A[:, e:, e:].baddbmm_(r[:, :, :n - e].transpose(1, 2), r, alpha=-1.0)
+    X = torch.empty((B, n, m), dtype=torch.float32, device=K.device)
+    for s in range(len(steps) - 1, -1, -1):                       # L^T X = Y, block rows from the bottom up
         j, e = steps[s]
         w = e - j
-        X[:, j:e] = torch.bmm(W[:, s, :w, :w].transpose(1, 2), X[:, j:e])
-        if j > 0:
-            X[:, :j].baddbmm_(K[:, j:e, :j].transpose(1, 2), X[:, j:e], alpha=-1.0)
+        r = R[s]
+        t = r[:, :, n - e:]
+        if e < n:
+            t = torch.baddbmm(t, r[:, :, :n - e], X[:, e:], alpha=-1.0)
+        torch.bmm(W[:, s, :w, :w].transpose(1, 2), t, out=X[:, j:e])
     return X
 
 
