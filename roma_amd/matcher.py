@@ -276,6 +276,18 @@ class Decoder(nn.Module):
         self.amp_dtype = amp_dtype
         self._proj = None
 
+    def _embedding_decoder_for(self, dtype):
+        if dtype == torch.float32:
+            return self.embedding_decoder
+        key = (dtype, _params_version(self.embedding_decoder))
+        hit = self.__dict__.get("_embed_cast")
+        if hit is None or hit[0] != key:
+            import copy
+            with torch.inference_mode(False), torch.no_grad():
+                hit = (key, copy.deepcopy(self.embedding_decoder).to(dtype).eval())
+            self.__dict__["_embed_cast"] = hit
+        return hit[1]
+
     def get_placeholder_flow(self, b, h, w, device):
         return pixel_grid(b, h, w, device)
 
@@ -352,10 +364,11 @@ class Decoder(nn.Module):
                 mu = self.gps[s].posterior_rows(xs.float().contiguous(), ys.float().contiguous(), hs, ws,
                                                 fp64=(dtype == torch.float32))                # :377
                 tokens = torch.cat((mu.to(dtype), xs), dim=2)                                 # transformer/__init__.py:35-41
-                # fp32 parameters, amp-dtype GEMMs/attention with fp32 LayerNorm/softmax: the reference's autocast
-                # region (transformer/__init__.py:31-32), here only around the library transformer
-                with torch.autocast("cuda", enabled=dtype != torch.float32, dtype=dtype if dtype != torch.float32 else None):
-                    rows = self.embedding_decoder.forward_rows(tokens)                        # (b, hw, 4097)
+                # The reference runs this transformer under autocast (transformer/__init__.py:31-32): fp32 parameters, amp-dtype
+                # GEMMs / attention.  Autocast re-casts every weight on every call (0.26 ms of copy kernels per pair), so the
+                # 16-bit modes run a cached amp-dtype copy of the module instead, like the DINOv2 trunk (LayerNorm and
+                # softmax still accumulate in fp32 inside their kernels).
+                rows = self._embedding_decoder_for(dtype).forward_rows(tokens)                # (b, hw, 4097)
                 flow, certainty = ops.cls_rows_to_flow(rows, b, hs, ws)                       # :378-385
             flow, certainty = refiner.forward_update(                                         # :393-402
                 x, y, flow, certainty, scale_factor, ins / (self.refine_init * w), ins / (self.refine_init * h), dtype=dtype, buf=buf)
