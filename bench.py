@@ -1,44 +1,72 @@
 #!/usr/bin/env python3
 """bench.py — image-pairs/s of RegressionMatcher.match() at 560->864 on N MI355X (BASELINE.json metric), plus the
-HBM roofline of the local_correlation kernel and a CPU baseline timed on the same box.
+HBM roofline of the local_correlation kernel, a CPU baseline timed on the same box and the parity of what is timed.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W [--workload outdoor|indoor_sample|tiny] [--pairs P]
 
-step     = one pass of the hot path (symmetric coarse 560 pass + 864 upsample pass + post-processing) over
-           --pairs synthetic image pairs per GPU, inputs already resident in HBM, outputs left on the device;
-           for N>1 the per-rank results are gathered to rank 0 (the path's only exchange step) inside the step.
-workload = BASELINE.json configs[1]: roma_outdoor 560->864 full coarse-to-fine, batch=1 per GPU, random-init weights of the
-           shipped architecture (no checkpoints offline), fp16 autocast semantics of the reference's GPU path.
-roofline = local_correlation: algorithmic bytes (f0+f1+flow+out) of the 5 launches per step / their
-           HIP-event durations on the launch stream, against 8 TB/s.
+N > 1: when WORLD_SIZE is not set, bench.py launches its own ranks (`python -m torch.distributed.run --nproc-per-node N
+bench.py ...`, one rank per GPU, as a child process) and relays rank 0's JSON line; under an external torchrun it is a
+rank.  N ranks need N devices; ROMA_BENCH_REHEARSAL=1 (with ROMA_BENCH_BACKEND=gloo) allows ranks to share a device for a
+dry run and tags the line `"rehearsal": true` with n_gpus = the number of DISTINCT devices.
+
+step     = one pass of the hot path over --pairs synthetic image pairs per GPU, inputs already resident in HBM, outputs
+           left on the device; for N>1 the per-rank results are gathered to rank 0 (the path's only exchange step) inside
+           the step.
+workloads (BASELINE.json configs):
+  outdoor       configs[1] (default; configs[2] = the same with --pairs 8 --gpus 8): roma_outdoor 560->864 full
+                coarse-to-fine symmetric match, fp16 autocast semantics of the reference's GPU path
+  indoor_sample configs[3]: roma_indoor (same architecture) 560->864, 8 pairs per step, + sample(num=10000) per pair
+  tiny          configs[4]: tiny_roma_v1 (XFeat-topology backbone) on 256 pairs of 480x640 per step
+roofline = local_correlation: algorithmic bytes (f0+f1+flow+out) of its launches in the timed region / their
+           HIP-event durations on the launch stream, against 8 TB/s (tiny: the fused corr+soft-argmax MFMA kernel, fp32 MFMA peak).
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK = 8.0e12   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK = 8.0e12        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK = 157.3e12  # same guide: fp32 MFMA = fp32 vector peak
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_model(device, dtype):
-    from roma_amd.model_zoo import build_roma
-    from roma_amd.synthetic import load_synthetic_weights
-    model = build_roma((560, 560), upsample_preds=True, amp_dtype=dtype)
-    load_synthetic_weights(model, seed=0)
-    model.upsample_res = (864, 864)
-    return model.to(device).eval()
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="outdoor", choices=["outdoor", "indoor_sample", "tiny"])
+    ap.add_argument("--pairs", type=int, default=0, help="image pairs per GPU per step (weak scaling); 0 = the workload's default (1 / 8 / 256)")
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16", "fp32"])
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / parity legs")
+    ap.add_argument("--no-microbench", action="store_true", help="skip the standalone local_corr launches (for --pmc passes over the pipeline only)")
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args) -> int:
+    """--gpus N without a torchrun environment: start the N ranks as a CHILD process (never exec: this process may not
+    touch the GPU before, and the parent stays a plain relay), pass rank 0's stdout through, return the child's exit code."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"[bench] launching {args.gpus} ranks: {' '.join(cmd)}")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def host_cores():
@@ -58,14 +86,29 @@ def host_cores():
 
 
 PARITY_IMAGES = [os.path.join(ROOT, "tests", "golden", "assets", f"sacre_coeur_{n}.jpg") for n in "AB"]
+WEIGHTS_NOTE = ("roma_amd.synthetic.load_synthetic_weights(seed=0): N(0, 1/fan_in) weights, non-trivial BatchNorm statistics, to_out x6, "
+                "pos_conv x4 (no checkpoints offline; SURVEY §8(d) suggests torch default init — either way random weights give "
+                "spatially INCOHERENT flow, which is the slow regime of local_corr)")
+INPUTS_NOTE = ("roma_amd.synthetic.synthetic_pair(i): smooth random texture + known similarity warp, generator seed 1234+i, "
+               "ImageNet-normalised statistics (SURVEY §8(d) prescribes N(0,1) tensors with the same seeds)")
 
 
-def cpu_baseline(gpu_fp32_result, budget_s=240, images=None):
-    """The oracle (CPU port of the reference path, oracle/roma_oracle.py) on ONE full 560->864 pair on the box's host
-    cores, in a fresh CPU-only child process (oracle/cpu_baseline.py) with a hard time budget; also the parity gate."""
-    import subprocess
+def build_model(device, dtype):
+    import torch  # noqa: F401
+    from roma_amd.model_zoo import build_roma
+    from roma_amd.synthetic import load_synthetic_weights
+    model = build_roma((560, 560), upsample_preds=True, amp_dtype=dtype)
+    load_synthetic_weights(model, seed=0)
+    model.upsample_res = (864, 864)
+    return model.to(device).eval()
+
+
+def run_oracle(images, budget_s=300):
+    """The oracle (CPU port of the reference path, oracle/roma_oracle.py) on ONE full 560->864 pair on the box's host cores,
+    in a fresh CPU-only child process (oracle/cpu_baseline.py) with a hard time budget.  Returns (cpu_baseline, warp, cert)."""
     import tempfile
     import numpy as np
+    import torch
     cores = host_cores()
     out = tempfile.mkdtemp(prefix="roma_cpu_")
     log(f"[bench] cpu_baseline: oracle 560->864, {cores} threads, budget {budget_s}s ...")
@@ -77,19 +120,54 @@ def cpu_baseline(gpu_fp32_result, budget_s=240, images=None):
         subprocess.run(cmd, cwd=ROOT, env=env, check=True, timeout=budget_s)
     except (subprocess.TimeoutExpired, subprocess.CalledProcessError) as e:
         log(f"[bench] cpu_baseline did not finish: {e!r}")
-        return None, None
+        return None, None, None
     meta = json.load(open(os.path.join(out, "cpu_baseline.json")))
     what = "the sacre_coeur photograph pair (tests/golden/assets)" if images else "1 synthetic pair"
     res = {"value": 1.0 / meta["seconds"], "unit": "image-pairs/s", "cores": meta["threads"], "kind": "port",
            "sample": f"{what}, full 560->864 symmetric match, oracle/roma_oracle.py fp32, {meta['seconds']:.1f} s"}
-    parity = None
-    if gpu_fp32_result is not None:
-        gw, gc = gpu_fp32_result
-        dw = (gw.cpu()[0] - torch.from_numpy(np.load(os.path.join(out, "warp.npy")))[0]).abs()
-        dc = (gc.cpu()[0] - torch.from_numpy(np.load(os.path.join(out, "certainty.npy")))[0]).abs()
-        parity = {"mode": "fp32", "inputs": "sacre_coeur_A/B.jpg" if images else "synthetic pair 0", "warp_max_abs": float(dw.max()), "certainty_max_abs": float(dc.max()),
-                  "warp_frac_gt_1e-3": float((dw > 1e-3).float().mean()), "tolerance": 1e-3}
-    return res, parity
+    return res, torch.from_numpy(np.load(os.path.join(out, "warp.npy"))), torch.from_numpy(np.load(os.path.join(out, "certainty.npy")))
+
+
+def diff_stats(gw, gc, rw, rc):
+    dw = (gw.float().cpu()[0] - rw[0]).abs()
+    dc = (gc.float().cpu()[0] - rc[0]).abs()
+    return {"warp_max_abs": float(dw.max()), "warp_median_abs": float(dw.median()), "warp_frac_gt_1e-3": float((dw > 1e-3).float().mean()),
+            "certainty_max_abs": float(dc.max()), "certainty_median_abs": float(dc.median()),
+            "certainty_frac_gt_1e-3": float((dc > 1e-3).float().mean())}
+
+
+def parity_legs(device, dtype, pin, images):
+    """Parity of the product path against the CPU oracle on the same inputs / weights (bar: 1e-3 max-abs, BASELINE.json):
+      parity      — fp32 mode through the PRODUCT GP kernels (fp32-MFMA CosKernel + blocked Cholesky) and, beside it, with the
+                    GP in torch fp64 (which removes this side's share of the ill-conditioned solve's rounding);
+      parity_fp16 — the mode that is TIMED (fp16: the reference's GPU autocast semantics) against the same oracle run, plus
+                    the number of scale-16 arg-max flips against the fp32 mode (cls_to_flow_refine's 4096-way arg-max is the
+                    path's one discontinuity)."""
+    import torch
+    cpu, rw, rc = run_oracle(images)
+    if cpu is None:
+        return None, None, None
+    res = {}
+    arg = {}
+    for name, dt, gp in (("fp32", torch.float32, "fp32"), ("fp32_gp64", torch.float32, "fp64"), ("timed", dtype, "fp32")):
+        m = build_model(device, dt)
+        m.decoder.gp_precision = gp
+        m.decoder.record = {}
+        w, c = m.match_tensors(*pin)
+        torch.cuda.synchronize()
+        res[name] = diff_stats(w, c, rw, rc)
+        arg[name] = m.decoder.record.get("argmax16")
+        del m
+        torch.cuda.empty_cache()
+    tol = 1e-3
+    parity = dict(res["fp32"], mode="fp32", gp="fp32-MFMA CosKernel + blocked Cholesky (product kernels)", tolerance=tol,
+                  inputs="sacre_coeur_A/B.jpg" if images else "synthetic pair 0", weights="synthetic seed 0",
+                  with_fp64_gp=res["fp32_gp64"])
+    flips = int((arg["timed"] != arg["fp32"]).sum()) if arg["timed"] is not None and arg["fp32"] is not None else None
+    p16 = dict(res["timed"], mode={torch.float16: "fp16", torch.bfloat16: "bf16", torch.float32: "fp32"}[dtype], vs="CPU oracle fp32 (the cpu_baseline run)",
+               argmax16_flips_vs_fp32_mode=flips, argmax16_total=int(arg["fp32"].numel()) if arg["fp32"] is not None else None, tolerance=tol,
+               note="decoder transformer: fp32 token/residual stream, 16-bit GEMMs/attention/logits (transformer/__init__.py:30-46)")
+    return cpu, parity, p16
 
 
 LC_SHAPES = [("L16", 512, 40, 7), ("L8", 512, 70, 3), ("L4", 256, 140, 2), ("U8", 512, 108, 3), ("U4", 256, 216, 2)]
@@ -100,6 +178,7 @@ def local_corr_microbench(device, dtype, pairs, iters=20):
     (identity grid o affine(rot 10 deg, scale 1.1, shift 0.05) + N(0, (0.5 px)^2)) and with U(-1.2,1.2) (adversarial
     floor).  A trained matcher produces coherent flow; random-init weights (what the timed pipeline runs) do not."""
     import math
+    import torch
     from roma_amd import ops
     es = 4 if dtype == torch.float32 else 2
     out = {}
@@ -148,23 +227,134 @@ def local_corr_microbench(device, dtype, pairs, iters=20):
     return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs", type=int, default=1, help="image pairs per GPU per step (weak scaling)")
-    ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16", "fp32"])
-    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / parity leg")
-    ap.add_argument("--no-microbench", action="store_true", help="skip the standalone local_corr launches (for --pmc passes over the pipeline only)")
-    args = ap.parse_args()
+def kernel_source_sha1():
+    return hashlib.sha1(open(os.path.join(ROOT, "roma_amd", "csrc", "local_corr.hip"), "rb").read()).hexdigest()
 
+
+def measured_traffic():
+    """HBM bytes per launch from the separate rocprofv3 --pmc passes (profiles/local_corr_traffic.json, tools/pmc_traffic.py).
+    Only trusted when it was collected for the local_corr.hip this run executes (sha1 stamp); else null + a note."""
+    pmc = os.path.join(ROOT, "profiles", "local_corr_traffic.json")
+    if not os.path.exists(pmc):
+        return None, "no profiles/local_corr_traffic.json"
+    d = json.load(open(pmc))
+    if d.get("kernel_source_sha1") != kernel_source_sha1():
+        return None, "profiles/local_corr_traffic.json was collected for a different local_corr.hip (sha1 mismatch): stale, not reported"
+    return d.get("hbm_bytes_per_launch"), f"rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes, {d.get('dispatches')} dispatches (profiles/local_corr_traffic.json)"
+
+
+def make_workload(args, device, dtype, rank, P):
+    """Returns (step_fn, config dict, model-ish handle, pinned parity inputs builder)."""
+    import torch
+    from roma_amd.synthetic import synthetic_pair
+    if args.workload in ("outdoor", "indoor_sample"):
+        model = build_model(device, dtype)
+        first = rank * P
+        pairs = [synthetic_pair(first + i) for i in range(P)]
+        A_lo, B_lo, A_hi, B_hi = (torch.cat([p[j] for p in pairs]).to(device) for j in range(4))
+        if args.workload == "outdoor":
+            def step():
+                return model.match_tensors(A_lo, B_lo, A_hi, B_hi)
+            cfg = {"workload": "roma_outdoor 560->864 full coarse-to-fine symmetric match (BASELINE configs[1]; configs[2] = --pairs 8 --gpus 8)"}
+        else:
+            it = [rank]
+
+            def step():
+                it[0] += 1
+                warp, cert = model.match_tensors(A_lo, B_lo, A_hi, B_hi)
+                samples = [model.sample(warp[i], cert[i], num=10000, seed=1234 + 1000 * it[0] + i) for i in range(P)]
+                return warp, cert, samples
+            cfg = {"workload": "roma_indoor 560->864 symmetric match + sample(num=10000) per pair (BASELINE configs[3]); roma_indoor is the "
+                               "roma_outdoor architecture with other weights (model_zoo/__init__.py:54-73)", "sample_num": 10000,
+                   "sample_mode": model.sample_mode}
+        cfg.update(coarse_res=560, upsample_res=864, weights=WEIGHTS_NOTE, inputs=INPUTS_NOTE)
+        return step, cfg, model, (A_lo, B_lo, A_hi, B_hi)
+    # tiny
+    from roma_amd.tiny import TinyRoMa, XFeatBackbone
+    from roma_amd.synthetic import synthetic_state_dict
+    xf = XFeatBackbone()
+    xf.load_state_dict(synthetic_state_dict({k: v.shape for k, v in xf.state_dict().items()}, seed=0), strict=True)
+    model = TinyRoMa(xf.eval(), freeze_xfeat=True, exact_softmax=False)
+    model.load_state_dict(synthetic_state_dict({k: v.shape for k, v in model.state_dict().items()}, seed=0))
+    model = model.to(device).eval()
+    xf.to(device)
+    g = torch.Generator().manual_seed(1234 + rank)
+    im0 = torch.rand(P, 3, 480, 640, generator=g).to(device)
+    im1 = torch.rand(P, 3, 480, 640, generator=g).to(device)
+
+    def step():
+        return model.match(im0, im1, batched=True)
+    cfg = {"workload": "tiny_roma_v1 (XFeat-topology backbone, synthetic weights) match() on 480x640 pairs (BASELINE configs[4])",
+           "resolution": [480, 640], "inputs": "U(0,1) images, generator seed 1234+rank", "weights": "synthetic seed 0; XFeat backbone = the "
+           "published topology restated in roma_amd/tiny.py (hub repository absent offline; backbone parity unpinned)"}
+    return step, cfg, model, None
+
+
+def stub_main(args, world, rank):
+    """ROMA_BENCH_STUB=1: the launcher / rendezvous / barrier / max-over-ranks / gather / JSON plumbing of this file with a
+    stand-in step on the CPU over gloo — what tests/test_dist_gloo.py runs where there is no GPU.  Never a measurement."""
+    import torch
+    import torch.distributed as dist
+    from roma_amd.dist import gather_results
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    P = args.pairs or 1
+
+    def step():
+        warp = torch.full((P, 4, 8, 4), float(rank))
+        cert = torch.full((P, 4, 8), float(rank))
+        return gather_results(warp, cert, world * P, dst=0) if world > 1 else (warp, cert)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank == 0:
+        order_ok = all(float(out[0][i * P, 0, 0, 0]) == float(i) for i in range(world))
+        print(json.dumps({"metric": "image-pairs/sec at 560->864", "value": world * P * args.steps / elapsed, "unit": "image-pairs/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "synthetic",
+                          "config": {"workload": "STUB (no GPU work): launcher / collective plumbing only", "gather_order_ok": order_ok},
+                          "stub": True}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))          # before anything in this process touches the GPU
+
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
+    if os.environ.get("ROMA_BENCH_STUB", "0") == "1":
+        return stub_main(args, world, rank)
+    ndev = torch.cuda.device_count()                  # does not initialise the GPU
+    rehearsal = os.environ.get("ROMA_BENCH_REHEARSAL", "0") == "1"
+    if ndev == 0:
         raise SystemExit("bench.py needs an MI355X: no ROCm device is visible (there is no CPU fallback path)")
-    ndev = torch.cuda.device_count()
+    if world > ndev and not rehearsal:
+        raise SystemExit(f"bench.py: {world} ranks but only {ndev} device(s) visible — one rank per GPU (ROMA_BENCH_REHEARSAL=1 "
+                         f"with ROMA_BENCH_BACKEND=gloo allows a dry run on shared devices)")
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no ROCm device is usable")
     torch.cuda.set_device(local_rank % ndev)
     device = torch.device("cuda", local_rank % ndev)
     import torch.distributed as dist
@@ -175,32 +365,28 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
-    if args.gpus != world and rank == 0:
-        log(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}")
 
     from roma_amd import ops
     from roma_amd.dist import gather_results
-    from roma_amd.synthetic import synthetic_pair
     dtype = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": torch.float32}[args.dtype]
-    do_cpu = (rank == 0 and world == 1 and not args.no_cpu)
+    if args.workload == "tiny":
+        dtype = torch.float32                               # TinyRoMa runs fp32 (no autocast in tiny.py:330-367)
+    do_cpu = (rank == 0 and world == 1 and not args.no_cpu and args.workload == "outdoor")
     torch.set_grad_enabled(False)
     t0 = time.time()
     torch.set_num_threads(host_cores())
-    model = build_model(device, dtype)
-    log(f"[bench] rank {rank}: model built in {time.time()-t0:.1f}s")
-
-    P = args.pairs
-    first = rank * P
-    pairs = [synthetic_pair(first + i) for i in range(P)]
-    A_lo, B_lo, A_hi, B_hi = (torch.cat([p[j] for p in pairs]).to(device) for j in range(4))
+    P = args.pairs or {"outdoor": 1, "indoor_sample": 8, "tiny": 256}[args.workload]
+    run, cfg, model, resident = make_workload(args, device, dtype, rank, P)
+    log(f"[bench] rank {rank}: workload {args.workload} built in {time.time()-t0:.1f}s")
 
     def step():
-        warp, cert = model.match_tensors(A_lo, B_lo, A_hi, B_hi)
+        out = run()
         if world > 1:
+            warp, cert = out[0], out[1]
             if backend != "nccl":                       # rehearsal path: gloo gathers host tensors
                 warp, cert = warp.cpu(), cert.cpu()
-            warp, cert = gather_results(warp, cert, world * P, dst=0)
-        return warp, cert
+            gather_results(warp, cert, world * P, dst=0)
+        return out
 
     for _ in range(args.warmup):
         step()
@@ -211,7 +397,7 @@ def main():
     ops.TIMER.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = step()
+        step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -222,25 +408,52 @@ def main():
         tt = torch.tensor([elapsed], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        devs = [None] * world
+        dist.all_gather_object(devs, f"{os.uname().nodename}:{local_rank % ndev}")
+        n_distinct = len(set(devs))
+    else:
+        n_distinct = 1
 
     if rank == 0:
-        lc = ops.TIMER.summary().get("local_corr")
+        summ = ops.TIMER.summary()
         roof = None
-        if lc:
-            a = lc["bytes"] / lc["seconds"]
-            roof = {"bound": "hbm", "kernel": "local_corr_kernel", "achieved": a / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                    "frac": a / HBM_PEAK, "traffic": None, "launches": lc["launches"],
-                    "event_bracket_overhead_us": ops.TIMER.bracket_overhead_s * 1e6,
-                    "avg_launch_us": lc["seconds"] / lc["launches"] * 1e6, "algorithmic_bytes_per_launch": lc["bytes"] / lc["launches"],
-                    "per_shape": {k: {"us": v[2] / v[0] * 1e6, "GB/s": v[1] / v[2] / 1e9} for k, v in sorted(lc["by_tag"].items())}}
-            pmc = os.path.join(ROOT, "profiles", "local_corr_traffic.json")
-            if os.path.exists(pmc):          # HBM bytes per launch from a separate rocprofv3 --pmc pass (see profiles/README.md)
-                roof["traffic"] = json.load(open(pmc)).get("hbm_bytes_per_launch")
-        micro = None if args.no_microbench else local_corr_microbench(device, dtype, P)
-        cpu = parity = None
+        if args.workload == "tiny":
+            tc = summ.get("tiny_corr")
+            if tc:
+                a = tc["bytes"] / tc["seconds"]              # "bytes" carries FLOPs for this MFMA-bound kernel
+                roof = {"bound": "mfma", "kernel": "tiny_corr_kernel", "achieved": a / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
+                        "frac": a / MFMA_F32_PEAK, "traffic": None, "launches": tc["launches"],
+                        "avg_launch_us": tc["seconds"] / tc["launches"] * 1e6, "algorithmic_flops_per_launch": tc["bytes"] / tc["launches"]}
+        else:
+            lc = summ.get("local_corr")
+            if lc:
+                a = lc["bytes"] / lc["seconds"]
+                traffic, tnote = measured_traffic() if args.workload == "outdoor" and P == 1 else (None, "collected for the default workload only")
+                roof = {"bound": "hbm", "kernel": "local_corr_kernel", "achieved": a / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                        "frac": a / HBM_PEAK, "traffic": traffic, "traffic_note": tnote, "launches": lc["launches"],
+                        "event_bracket_overhead_us": ops.TIMER.bracket_overhead_s * 1e6,
+                        "avg_launch_us": lc["seconds"] / lc["launches"] * 1e6, "algorithmic_bytes_per_launch": lc["bytes"] / lc["launches"],
+                        "flow": "as produced by the timed pipeline (random-init weights => incoherent; see roofline_microbench for the "
+                                "SURVEY §8(d) coherent-flow protocol)",
+                        "per_shape": {k: {"us": v[2] / v[0] * 1e6, "GB/s": v[1] / v[2] / 1e9} for k, v in sorted(lc["by_tag"].items())}}
+        micro = None
+        if not args.no_microbench and args.workload == "outdoor":
+            micro = local_corr_microbench(device, dtype, P)
+        extra = {}
+        if args.workload == "indoor_sample":
+            # the same pairs without the sampling stage, for the "with and without sampling" report of SURVEY §8(d)
+            A_lo, B_lo, A_hi, B_hi = resident
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n_ns = max(2, args.steps // 4)
+            for _ in range(n_ns):
+                model.match_tensors(A_lo, B_lo, A_hi, B_hi)
+            torch.cuda.synchronize()
+            extra["ms_per_step_without_sample"] = (time.perf_counter() - t1) / n_ns * 1e3
+        cpu = parity = parity16 = None
         if do_cpu:
-            # parity gate + CPU baseline on a real photograph pair when the fixture images are present (the decoder's
-            # arg-max makes near-tied synthetic textures flip coarse pixels between ANY two fp32 implementations)
+            # parity + CPU baseline on a real photograph pair when the fixture images are present (the decoder's arg-max makes
+            # near-tied synthetic textures flip coarse pixels between ANY two fp32 implementations)
             images = PARITY_IMAGES if all(os.path.exists(f) for f in PARITY_IMAGES) else None
             if images:
                 from PIL import Image
@@ -248,24 +461,25 @@ def main():
                 ims = [Image.open(f).convert("RGB") for f in images]
                 pin = [preprocess(im, (560, 560))[None].to(device) for im in ims] + [preprocess(im, (864, 864))[None].to(device) for im in ims]
             else:
-                pin = [A_lo[:1], B_lo[:1], A_hi[:1], B_hi[:1]]
-            del model                                    # its ViT weights were cast to the amp dtype in place
+                pin = [t[:1] for t in resident]
+            del model, run                               # free the timed model before the three parity models are built
             torch.cuda.empty_cache()
-            model32 = build_model(device, torch.float32)
-            g32 = model32.match_tensors(*pin)
-            torch.cuda.synchronize()
-            del model32
-            cpu, parity = cpu_baseline(g32, images=images)
+            cpu, parity, parity16 = parity_legs(device, dtype, pin, images)
         total_pairs = world * P * args.steps
+        cfg.update(pairs_per_gpu_per_step=P, global_pairs_per_step=world * P,
+                   parallelism=f"pair-sharded x{world}, one ordered gather of (warp, certainty) to rank 0 per step" if world > 1 else "single GPU")
+        cfg.update(extra)
         line = {
-            "metric": "image-pairs/sec at 560->864", "value": total_pairs / elapsed, "unit": "image-pairs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "roma_outdoor 560->864 full coarse-to-fine symmetric match, random-init weights",
-                       "pairs_per_gpu_per_step": P, "global_pairs_per_step": world * P, "coarse_res": 560, "upsample_res": 864,
-                       "parallelism": f"pair-sharded x{world}, gather of (warp, certainty) to rank 0" if world > 1 else "single GPU"},
-            "roofline": roof, "roofline_microbench": micro, "cpu_baseline": cpu, "parity": parity,
+            "metric": "image-pairs/sec at 560->864" if args.workload != "tiny" else "image-pairs/sec at 480x640 (tiny_roma_v1)",
+            "value": total_pairs / elapsed, "unit": "image-pairs/s",
+            "n_gpus": n_distinct if rehearsal else world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {torch.float16: "fp16", torch.bfloat16: "bf16", torch.float32: "fp32"}[dtype],
+            "data": "synthetic", "config": cfg,
+            "roofline": roof, "roofline_microbench": micro, "cpu_baseline": cpu, "parity": parity, "parity_fp16": parity16,
         }
+        if rehearsal:
+            line["rehearsal"] = True
+            line["ranks"] = world
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

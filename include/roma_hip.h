@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ROMA_ABI_VERSION 1
+#define ROMA_ABI_VERSION 2
 
 enum { ROMA_F32 = 0, ROMA_F16 = 1, ROMA_BF16 = 2 };
 enum { ROMA_NCHW = 0, ROMA_NHWC = 1 };
@@ -41,16 +41,18 @@ const char* roma_last_error(void);
  *   align_corners=False, k = iy*(2r+1)+ix, delta_k = ((ix-r)*2/W, (iy-r)*2/H).
  *   flow: (B,2,H,W) fp32 planar, (x,y) in [-1,1]; NULL = identity grid (local_correlation.py:16-27).
  *   f0,f1: `dtype`, `layout`, pitches f0_pitch/f1_pitch.  out: K=(2r+1)^2 channels, `dtype`, out_layout/out_pitch.
- *   r in {1..7}. */
+ *   r in {1..7}.  f1_batch_shift: f0's item b is correlated with f1's item (b + f1_batch_shift) % B — B/2 for
+ *   forward_symmetric (matcher.py:516-528), whose second operand is the first with its batch halves swapped; 0 otherwise. */
 int roma_local_corr(const void* f0, const void* f1, const float* flow, void* out,
                     int B, int C, int H, int W, int r, int dtype,
-                    int layout, int f0_pitch, int f1_pitch, int out_layout, int out_pitch, void* stream);
+                    int layout, int f0_pitch, int f1_pitch, int out_layout, int out_pitch, int f1_batch_shift, void* stream);
 
 /* F.grid_sample(y, flow^T, mode=bilinear, padding zeros, align_corners=False) — matcher.py:109 (ConvRefiner warp),
- * tiny.py:357,363.  src: (B,C,Hs,Ws); flow (B,2,H,W) fp32 planar; dst: (B,C,H,W).  Layout/pitch rules as above. */
+ * tiny.py:357,363.  src: (B,C,Hs,Ws); flow (B,2,H,W) fp32 planar; dst: (B,C,H,W).  Layout/pitch rules as above.
+ * dst item b samples src item (b + src_batch_shift) % B (see roma_local_corr). */
 int roma_warp_bilinear(const void* src, const float* flow, void* dst,
                        int B, int C, int Hs, int Ws, int H, int W, int dtype,
-                       int layout, int src_pitch, int dst_layout, int dst_pitch, void* stream);
+                       int layout, int src_pitch, int dst_layout, int dst_pitch, int src_batch_shift, void* stream);
 
 /* displacement embedding — matcher.py:111-120: emb = Conv1x1(2->E)(gain * (flow - identity_grid)), gain = 40/32*scale_factor.
  *   weight (E,2) fp32, bias (E) fp32, flow (B,2,H,W) fp32, dst E channels of `dtype` in dst_layout/dst_pitch. */
@@ -77,18 +79,23 @@ int roma_cls_to_flow_refine(const void* logits, float* flow_out, float* cert_out
                             int B, int C, int HW, long stride_b, long stride_c, long stride_p,
                             int dtype, void* stream);
 
-/* CosKernel — matcher.py:154-163:  K[b,n,m] = exp((<x_n,y_m>/(|x_n||y_m| + eps) - 1)/T), fp32 in / fp32 out on the
- * exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).  x: (B,N,D) row-major, y: (B,M,D) row-major, K: (B,N,M).
- * D a multiple of 16.  `diag_add` is added to K[b,i,i] when x == y (GP.forward's K_yy + sigma*I, matcher.py:259-261). */
-int roma_cos_kernel(const float* x, const float* y, float* K, int B, int N, int M, int D,
-                    float T, float eps, float diag_add, void* stream);
+/* CosKernel — matcher.py:154-163:  K[b,n,m] = exp((<x_n,y_m>/(|x_n||y_m| + eps) - 1)/T), fp32 arithmetic / fp32 out on the
+ * exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).  x: (B,N,·) rows of `dtype` with x_pitch elements between rows (so the D feature
+ * channels of a channels-last map can be read in place; 16-bit storage is widened exactly, i.e. the result equals the fp32
+ * kernel on x.float(), matcher.py:254), y: (B,M,·) likewise; item b of x meets item (b + y_batch_shift) % B of y.
+ * K: (B,N,M) fp32.  D a multiple of 16.  `diag_add` is added to K[b,i,i] (GP.forward's K_yy + sigma*I, matcher.py:259-261). */
+int roma_cos_kernel(const void* x, const void* y, float* K, int B, int N, int M, int D, int dtype, int x_pitch, int y_pitch,
+                    int y_batch_shift, float T, float eps, float diag_add, void* stream);
 
 /* One diagonal-block step of the blocked Cholesky solve that replaces GP.forward's inv(K_yy + sigma I) @ f —
  * matcher.py:259-263.  For each of the B matrices: the nb x nb block at A (row-major, leading dimension lda, batch stride
  * strideA; only its lower triangle is read) is replaced by its Cholesky factor L (lower), and W (nb x nb, ldw, strideW)
- * receives L^-1.  info[b] != 0 reports a non-positive pivot (1-based).  nb <= 64.  The panel and substitution steps
- * around it are plain GEMMs done by the caller (roma_amd/ops.py: spd_solve). */
-int roma_chol_diag_block(float* A, int lda, long strideA, float* W, int ldw, long strideW, int nb, int B, int* info, void* stream);
+ * receives L^-1.  A non-positive or NaN pivot p (0-based, within the block) is clamped and recorded: if info[b] == 0 it
+ * becomes info_base + p + 1, so a zero-initialised info keeps the FIRST failing pivot of a whole blocked solve (the
+ * reference's torch.linalg.inv raises in that case, matcher.py:261).  nb <= 64.  The panel and substitution steps around it
+ * are plain GEMMs done by the caller (roma_amd/ops.py: spd_solve). */
+int roma_chol_diag_block(float* A, int lda, long strideA, float* W, int ldw, long strideW, int nb, int B, int* info,
+                         int info_base, void* stream);
 
 /* match() post-processing — matcher.py:656-662, 684-718: certainty attenuation by the coarse scale-16 certainty,
  * sigmoid, zeroing where |flow|>1, clamp, symmetric concat.
@@ -98,9 +105,19 @@ int roma_chol_diag_block(float* A, int lda, long strideA, float* W, int ldw, lon
 int roma_match_finalize(const float* flow, const float* cert, const float* cert16, float* warp, float* certainty,
                         int P, int H, int W, int H16, int W16, int symmetric, void* stream);
 
-/* kde — romatch/utils/kde.py:4-12: density[i] = sum_j exp(-|x_i - x_j|^2 / (2 std^2)), x: (N,4) fp32 (already
- * rounded to fp16 values by the caller when half=True), ref points every `down`-th row.  density (N) fp32. */
-int roma_kde_density(const float* x, float* density, int N, int down, float std, void* stream);
+/* kde — romatch/utils/kde.py:4-12: density[i] = sum_j exp(-|x_i - x_j|^2 / (2 std^2)), x: (N,4) fp32, ref points every
+ * `down`-th row, density (N) fp32.  half_mode = 0: fp32 arithmetic (kde(half=False)).  half_mode = 1: x already holds
+ * fp16-representable values (the caller's x.half()) and every term goes through the rounding points of the reference's fp16
+ * evaluation (torch.cdist's matmul route in fp16, then fp16 **2, /, exp), summed in fp32 (the caller rounds the sum to fp16). */
+int roma_kde_density(const float* x, float* density, int N, int down, float std, int half_mode, void* stream);
+
+/* Exponential-race keys for sampling WITHOUT replacement — RegressionMatcher.sample (matcher.py:474-493), both of its
+ * torch.multinomial(..., replacement=False) draws:  w_i = (thresh >= 0 && p_i > thresh) ? 1 : p_i  (the "threshold" sample
+ * mode, matcher.py:474-477);  key_i = w_i / E_i with E_i = -ln(u_i) i.i.d. Exp(1); the k largest keys are a draw of k items
+ * without replacement with probabilities proportional to w (what multinomial does internally).  u_i comes from a counter
+ * hash of (seed, i) — u = ((fmix32(i * 0x9E3779B1 + seed * 0x85EBCA77 + 0x165667B1) >> 8) + 0.5) / 2^24, fmix32 = the
+ * MurmurHash3 finaliser — so a CPU oracle reproduces the draw.  p, keys: (N) fp32; w_i <= 0 (or NaN) gives key 0. */
+int roma_race_keys(const float* p, float* keys, long N, float thresh, unsigned seed, void* stream);
 
 /* Pre-processing on the device — utils.py:165-261 (TupleResize = PIL bicubic, ToTensorScaled, TupleNormalize), bit-identical
  * to the host path.  One pass of PIL's 8-bit resampling (Pillow Resample.c): out = clip8((2^21 + sum_k in[lo+k] * coef[k]) >> 22).
@@ -151,6 +168,19 @@ int roma_refiner_head(const void* x, const float* wo, const float* bo, float* fl
  *   (in, out), bias (C) fp32.  C a multiple of 8 (fp16/bf16) or 4 (fp32), C <= 32. */
 int roma_pointwise_small(const void* x, const float* wt, const float* bias, void* y, long M, int C, int dtype,
                          int x_pitch, int y_pitch, void* stream);
+
+/* Residual add (+ LayerScale) fused with the following LayerNorm — the seam between two transformer half-blocks
+ * (transformer/layers/block.py:87-107) and the fp32 token stream of the decoder transformer under autocast
+ * (transformer/__init__.py:30-46: cat(fp32 GP posterior, fp16 features) promotes to fp32; LayerNorm is fp32; GEMMs take
+ * 16-bit casts):
+ *     if (y) x[r,:] = round_to_x_dtype(x[r,:] + ls[:] * y[r,:])      (ls == NULL: plain add), written back in place
+ *     out[r,:] = gamma ? LayerNorm(x[r,:]; eps) * gamma + beta : x[r,:]     cast to out_dtype
+ *   x (rows, x_stride) of x_dtype; y (rows, y_stride) of y_dtype or NULL; ls, gamma, beta (C) fp32 or NULL; out (rows,
+ *   out_stride) of out_dtype.  Supported: fp32 stream with fp32/16-bit branch, 16-bit stream with a branch of the same
+ *   dtype.  C a multiple of 8, <= 2048; strides multiples of 8. */
+int roma_add_layernorm(void* x, int x_dtype, long x_stride, const void* y, int y_dtype, long y_stride, const float* ls,
+                       const float* gamma, const float* beta, void* out, int out_dtype, long out_stride, long rows, int C,
+                       float eps, void* stream);
 
 /* TinyRoMa corr_volume + pos_embed fused — tiny.py:241-254, 178-203: for every source pixel the soft-argmax target
  * coordinate over the full correlation row, without materialising the (H1W1 x H0W0) volume.

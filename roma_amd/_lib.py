@@ -10,24 +10,28 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libroma_hip.so")
 
 ROMA_F32, ROMA_F16, ROMA_BF16 = 0, 1, 2
 ROMA_NCHW, ROMA_NHWC = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # name -> argtypes; restype is c_int unless listed in _RESTYPES.  Mirrors include/roma_hip.h one to one.
 SIGNATURES = {
     "roma_abi_version": [],
     "roma_last_error": [],
     "roma_local_corr": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
-                        c_int, c_int, c_int, c_int, c_int, c_void_p],
+                        c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "roma_warp_bilinear": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                           c_int, c_int, c_int, c_int, c_void_p],
+                           c_int, c_int, c_int, c_int, c_int, c_void_p],
     "roma_disp_emb": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_int, c_void_p],
     "roma_interp_bilinear": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "roma_flow_update": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p],
     "roma_cls_to_flow_refine": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_long, c_long, c_int, c_void_p],
-    "roma_cos_kernel": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_void_p],
-    "roma_chol_diag_block": [c_void_p, c_int, c_long, c_void_p, c_int, c_long, c_int, c_int, c_void_p, c_void_p],
+    "roma_cos_kernel": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float,
+                        c_float, c_void_p],
+    "roma_add_layernorm": [c_void_p, c_int, c_long, c_void_p, c_int, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_long,
+                           c_long, c_int, c_float, c_void_p],
+    "roma_chol_diag_block": [c_void_p, c_int, c_long, c_void_p, c_int, c_long, c_int, c_int, c_void_p, c_int, c_void_p],
     "roma_match_finalize": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
-    "roma_kde_density": [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
+    "roma_kde_density": [c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p],
+    "roma_race_keys": [c_void_p, c_void_p, c_long, c_float, ctypes.c_uint, c_void_p],
     "roma_dwconv5x5_bn_relu": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "roma_resample_u8": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p],
     "roma_normalize_u8": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p],

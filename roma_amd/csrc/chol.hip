@@ -22,7 +22,7 @@ __device__ __forceinline__ float lane_bcast(float v, int src_lane) {
 }
 
 __global__ __launch_bounds__(64) void chol_diag_kernel(float* __restrict__ A, int lda, long strideA, float* __restrict__ W, int ldw,
-                                                       long strideW, int nb, int* __restrict__ info) {
+                                                       long strideW, int nb, int* __restrict__ info, int info_base) {
   __shared__ float Ls[NBMAX * NBMAX];
   const int r = threadIdx.x, b = blockIdx.x;
   float* Ab = A + (size_t)b * strideA;
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(64) void chol_diag_kernel(float* __restrict__ A, in
       a[c] = (r >= c) ? a[c] - lrk * lck : a[c];
     }
   }
-  if (r == 0 && bad != 0 && bad <= nb) info[b] = bad;
+  if (r == 0 && bad != 0 && bad <= nb && info[b] == 0) info[b] = info_base + bad;   // the FIRST failing pivot of the whole solve
 #pragma unroll
   for (int c = 0; c < NBMAX; ++c) Ls[r * NBMAX + c] = a[c];
   __syncthreads();
@@ -74,9 +74,9 @@ __global__ __launch_bounds__(64) void chol_diag_kernel(float* __restrict__ A, in
 using namespace roma;
 
 extern "C" int roma_chol_diag_block(float* A, int lda, long strideA, float* W, int ldw, long strideW, int nb, int B, int* info,
-                                    void* stream) {
+                                    int info_base, void* stream) {
   ROMA_REQUIRE(A && W && info, ROMA_E_ARG, "roma_chol_diag_block: null pointer");
   ROMA_REQUIRE(nb >= 1 && nb <= NBMAX && B >= 1 && lda >= nb && ldw >= nb, ROMA_E_SHAPE, "roma_chol_diag_block: bad shape nb=%d B=%d", nb, B);
-  hipLaunchKernelGGL(chol_diag_kernel, dim3(B), dim3(64), 0, static_cast<hipStream_t>(stream), A, lda, strideA, W, ldw, strideW, nb, info);
+  hipLaunchKernelGGL(chol_diag_kernel, dim3(B), dim3(64), 0, static_cast<hipStream_t>(stream), A, lda, strideA, W, ldw, strideW, nb, info, info_base);
   ROMA_CHECK_LAUNCH();
 }

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdint>
@@ -162,6 +163,20 @@ __device__ __forceinline__ void interp_src(int d, int in, int out, int& i0, int&
 __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
   const int q = nblocks >> 3, r = nblocks & 7, xcd = bid & 7, idx = bid >> 3;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE property of a kernel: opt it in once per (kernel, device).
+// `mask` is one static per call site (bit d = done on device d); racing threads at worst set the attribute twice.
+inline int ensure_dyn_smem(const void* fn, int bytes, std::atomic<uint64_t>& mask, const char* what) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) { set_error("%s: hipGetDevice: %s", what, hipGetErrorString(e)); return (int)e; }
+  const uint64_t bit = 1ull << (dev & 63);
+  if (mask.load(std::memory_order_acquire) & bit) return 0;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) { set_error("%s: hipFuncSetAttribute(%d bytes of LDS): %s", what, bytes, hipGetErrorString(e)); return (int)e; }
+  mask.fetch_or(bit, std::memory_order_release);
+  return 0;
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }

@@ -13,14 +13,27 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BT = 64, KT = 16, LD = KT + 1;
 
-__global__ __launch_bounds__(256) void cos_kernel_mfma(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ K,
-                                                       int N, int M, int D, float invT, float eps, float diag_add) {
+// 4 consecutive channels of a row as fp32 (16-bit storage converts exactly, so the result equals the fp32 kernel on x.float())
+template <typename T> __device__ __forceinline__ float4_t ld4(const T* p) {
+  if constexpr (sizeof(T) == 4) {
+    return *reinterpret_cast<const float4_t*>(p);
+  } else {
+    typedef T v4 __attribute__((ext_vector_type(4)));
+    const v4 h = *reinterpret_cast<const v4*>(p);
+    return float4_t{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cos_kernel_mfma(const T* __restrict__ x, const T* __restrict__ y, float* __restrict__ K,
+                                                       int N, int M, int D, int x_pitch, int y_pitch, int y_shift, float invT,
+                                                       float eps, float diag_add) {
   __shared__ float sA[BT * LD], sB[BT * LD], sN[2 * BT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int b = blockIdx.z, n0 = blockIdx.y * BT, m0 = blockIdx.x * BT;
-  const float* xb = x + (size_t)b * N * D;
-  const float* yb = y + (size_t)b * M * D;
+  const T* xb = x + (size_t)b * N * x_pitch;
+  const T* yb = y + (size_t)((b + y_shift) % (int)gridDim.z) * M * y_pitch;
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -28,8 +41,8 @@ __global__ __launch_bounds__(256) void cos_kernel_mfma(const float* __restrict__
   const int lr = tid >> 2, lc = (tid & 3) * 4;       // loader: row 0..63, 4 consecutive k
   for (int k0 = 0; k0 < D; k0 += KT) {
     float4_t va{0, 0, 0, 0}, vb{0, 0, 0, 0};
-    if (n0 + lr < N) va = *reinterpret_cast<const float4_t*>(xb + (size_t)(n0 + lr) * D + k0 + lc);
-    if (m0 + lr < M) vb = *reinterpret_cast<const float4_t*>(yb + (size_t)(m0 + lr) * D + k0 + lc);
+    if (n0 + lr < N) va = ld4<T>(xb + (size_t)(n0 + lr) * x_pitch + k0 + lc);
+    if (m0 + lr < M) vb = ld4<T>(yb + (size_t)(m0 + lr) * y_pitch + k0 + lc);
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -71,14 +84,24 @@ __global__ __launch_bounds__(256) void cos_kernel_mfma(const float* __restrict__
 
 using namespace roma;
 
-extern "C" int roma_cos_kernel(const float* x, const float* y, float* K, int B, int N, int M, int D, float T, float eps,
-                               float diag_add, void* stream) {
+extern "C" int roma_cos_kernel(const void* x, const void* y, float* K, int B, int N, int M, int D, int dtype, int x_pitch,
+                               int y_pitch, int y_batch_shift, float T, float eps, float diag_add, void* stream) {
   ROMA_REQUIRE(x && y && K, ROMA_E_ARG, "roma_cos_kernel: null pointer");
   ROMA_REQUIRE(B > 0 && N > 0 && M > 0 && D > 0, ROMA_E_SHAPE, "roma_cos_kernel: bad shape");
   ROMA_REQUIRE(D % KT == 0, ROMA_E_SHAPE, "roma_cos_kernel: D=%d must be a multiple of %d", D, KT);
-  ROMA_REQUIRE(aligned16(x) && aligned16(y), ROMA_E_ALIGN, "roma_cos_kernel: x and y must be 16-byte aligned");
+  ROMA_REQUIRE(x_pitch >= D && y_pitch >= D, ROMA_E_SHAPE, "roma_cos_kernel: row pitch smaller than D");
+  ROMA_REQUIRE(dtype >= ROMA_F32 && dtype <= ROMA_BF16, ROMA_E_DTYPE, "roma_cos_kernel: unknown dtype %d", dtype);
+  const int e16 = dtype == ROMA_F32 ? 4 : 8;
+  ROMA_REQUIRE(aligned16(x) && aligned16(y) && x_pitch % e16 == 0 && y_pitch % e16 == 0, ROMA_E_ALIGN,
+               "roma_cos_kernel: x and y must be 16-byte aligned with row pitches that keep every row 16-byte aligned");
+  ROMA_REQUIRE(y_batch_shift >= 0 && y_batch_shift < B, ROMA_E_ARG, "roma_cos_kernel: y_batch_shift %d outside [0, B)", y_batch_shift);
   ROMA_REQUIRE(T > 0.f, ROMA_E_ARG, "roma_cos_kernel: temperature must be positive");
   dim3 grid((M + BT - 1) / BT, (N + BT - 1) / BT, B);
-  hipLaunchKernelGGL(cos_kernel_mfma, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, y, K, N, M, D, 1.f / T, eps, diag_add);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define ROMA_COS(TT)                                                                                                         \
+  hipLaunchKernelGGL((cos_kernel_mfma<TT>), grid, dim3(256), 0, s, (const TT*)x, (const TT*)y, K, N, M, D, x_pitch, y_pitch, \
+                     y_batch_shift, 1.f / T, eps, diag_add)
+  if (dtype == ROMA_F32) ROMA_COS(float); else if (dtype == ROMA_F16) ROMA_COS(half_t); else ROMA_COS(bf16_t);
+#undef ROMA_COS
   ROMA_CHECK_LAUNCH();
 }

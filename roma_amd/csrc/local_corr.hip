@@ -26,6 +26,7 @@ struct LCParams {
   int f0_pitch, f1_pitch, out_pitch;
   int in_nhwc, out_nhwc;
   int tiles_x, tiles_y;
+  int f1_shift;  // f1 batch item paired with f0's item b is (b + f1_shift) % B (forward_symmetric: B/2)
   int max_rows;  // LDS capacity in f1 rows (excluding the zero row)
   float scale;   // C^-1/2
 };
@@ -143,6 +144,7 @@ __global__ __launch_bounds__(kThreads) void local_corr_kernel(LCParams p) {
 
   const T* f0 = static_cast<const T*>(p.f0);
   const T* f1 = static_cast<const T*>(p.f1);
+  const int b1 = (b + p.f1_shift) % p.B;
   if (staged) {                                                // zero row
     for (int i = tid; i < ROW16; i += kThreads) s_f1[zero_row * ROW16 + i] = u32x4{0, 0, 0, 0};
   }
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(kThreads) void local_corr_kernel(LCParams p) {
           const int y = by0 + row / bw, x = bx0 + row % bw;
           u32x4 v{0, 0, 0, 0};
           if (c0 + k * E16 < p.C)
-            v = *reinterpret_cast<const u32x4*>(f1 + feat_off(1, b, c0 + k * E16, y, x, p.f1_pitch, H, W));
+            v = *reinterpret_cast<const u32x4*>(f1 + feat_off(1, b1, c0 + k * E16, y, x, p.f1_pitch, H, W));
           s_f1[row * ROW16 + k] = v;
         }
       }
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(kThreads) void local_corr_kernel(LCParams p) {
           const int c = i / nrows, row = i - c * nrows;
           const int y = by0 + row / bw, x = bx0 + row % bw;
           T v = from_f32<T>(0.f);
-          if (c0 + c < p.C) v = f1[feat_off(0, b, c0 + c, y, x, p.f1_pitch, H, W)];
+          if (c0 + c < p.C) v = f1[feat_off(0, b1, c0 + c, y, x, p.f1_pitch, H, W)];
           s1[row * ROW16 * E16 + c] = v;
         }
       }
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(kThreads) void local_corr_kernel(LCParams p) {
           const int yy = rowoff[i] / W, xx = rowoff[i] - yy * W;
           float s = acc[i];
           if (p.in_nhwc) {
-            const T* src = f1 + feat_off(1, b, c0, yy, xx, p.f1_pitch, H, W);
+            const T* src = f1 + feat_off(1, b1, c0, yy, xx, p.f1_pitch, H, W);
 #pragma unroll 1
             for (int k = 0; k < PK; ++k)
               if (c0 + k * E16 < p.C)
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(kThreads) void local_corr_kernel(LCParams p) {
           } else {
 #pragma unroll 1
             for (int c = 0; c < CC && c0 + c < p.C; ++c)
-              s = __builtin_fmaf(to_f32(a_el[c]), to_f32(f1[feat_off(0, b, c0 + c, yy, xx, p.f1_pitch, H, W)]), s);
+              s = __builtin_fmaf(to_f32(a_el[c]), to_f32(f1[feat_off(0, b1, c0 + c, yy, xx, p.f1_pitch, H, W)]), s);
           }
           acc[i] = s;
         }
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(kThreads, 4) void local_corr_nhwc_kernel(LCParams p
     g16 = (tid >> 6) * 4 + (lane >> 5) * 2 + hg;
   }
   const T* f0 = static_cast<const T*>(p.f0) + (size_t)b * H * W * p.f0_pitch;
-  const T* f1 = static_cast<const T*>(p.f1) + (size_t)b * H * W * p.f1_pitch;
+  const T* f1 = static_cast<const T*>(p.f1) + (size_t)((b + p.f1_shift) % p.B) * H * W * p.f1_pitch;
 
   // The two modes are separate instantiations of one lambda so that each keeps its own (small) register set.
   // A work item = 16 consecutive window positions (one "iteration" it) of one pixel, reduced by one 16-lane group.
@@ -655,7 +657,7 @@ __global__ __launch_bounds__(kThreads, 2) void local_corr_mfma_kernel(LCParams p
     if (gm[2] >= gm[0] && gm[3] >= gm[1]) eligible = eligible && (gm[2] - gm[0] + 1 <= WC) && (gm[3] - gm[1] + 1 <= GHMAX);
   }
   const T* f0 = static_cast<const T*>(p.f0) + (size_t)b * H * W * p.f0_pitch;
-  const T* f1 = static_cast<const T*>(p.f1) + (size_t)b * H * W * p.f1_pitch;
+  const T* f1 = static_cast<const T*>(p.f1) + (size_t)((b + p.f1_shift) % p.B) * H * W * p.f1_pitch;
   T* out = static_cast<T*>(p.out);
   // LDS row of pixel (ty,tx)'s f0: group-major so that a group's 16 rows are consecutive (A fragment = one b128 each)
   auto frow = [&](int pix) { const int ty = pix / TW, tx = pix % TW; return (tx >> 2) * 16 + ty * 4 + (tx & 3); };
@@ -865,13 +867,8 @@ int launch_lc_mfma(LCParams p, hipStream_t stream) {
   p.tiles_y = (p.H + M::TH - 1) / M::TH;
   p.max_rows = M::MAXR;
   const size_t smem = (size_t)BODY16 * 16 + (size_t)M::TP * (Q + 1) * 4 + (8 + 4 * M::NG + 2 * M::TP) * 4 + 2 * M::TP * 4;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(local_corr_mfma_kernel<T, R>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) { set_error("roma_local_corr: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-    attr_done = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  if (int rc = ensure_dyn_smem(reinterpret_cast<const void*>(local_corr_mfma_kernel<T, R>), (int)smem, attr_done, "roma_local_corr")) return rc;
   const int grid = p.B * p.tiles_x * p.tiles_y;
   hipLaunchKernelGGL((local_corr_mfma_kernel<T, R>), dim3(grid), dim3(kThreads), smem, stream, p);
   ROMA_CHECK_LAUNCH();
@@ -929,11 +926,12 @@ int dispatch_r(const LCParams& p, int r, hipStream_t s) {
 
 extern "C" int roma_local_corr(const void* f0, const void* f1, const float* flow, void* out, int B, int C, int H, int W,
                                int r, int dtype, int layout, int f0_pitch, int f1_pitch, int out_layout, int out_pitch,
-                               void* stream) {
+                               int f1_batch_shift, void* stream) {
   using namespace roma;
   ROMA_REQUIRE(f0 && f1 && out, ROMA_E_ARG, "roma_local_corr: null pointer");
   ROMA_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, ROMA_E_SHAPE, "roma_local_corr: bad shape B=%d C=%d H=%d W=%d", B, C, H, W);
   ROMA_REQUIRE(r >= 1 && r <= 7, ROMA_E_UNSUPPORTED, "roma_local_corr: radius %d outside 1..7", r);
+  ROMA_REQUIRE(f1_batch_shift >= 0 && f1_batch_shift < B, ROMA_E_ARG, "roma_local_corr: f1_batch_shift %d outside [0, B)", f1_batch_shift);
   ROMA_REQUIRE(layout == ROMA_NCHW || layout == ROMA_NHWC, ROMA_E_ARG, "roma_local_corr: bad layout %d", layout);
   ROMA_REQUIRE(out_layout == ROMA_NCHW || out_layout == ROMA_NHWC, ROMA_E_ARG, "roma_local_corr: bad out_layout %d", out_layout);
   const int K = (2 * r + 1) * (2 * r + 1);
@@ -951,6 +949,7 @@ extern "C" int roma_local_corr(const void* f0, const void* f1, const float* flow
   p.f0_pitch = f0_pitch; p.f1_pitch = f1_pitch; p.out_pitch = out_pitch;
   p.in_nhwc = layout == ROMA_NHWC; p.out_nhwc = out_layout == ROMA_NHWC;
   p.scale = 1.0f / sqrtf((float)C);
+  p.f1_shift = f1_batch_shift;
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (dtype) {
     case ROMA_F32: return dispatch_r<float>(p, r, s);

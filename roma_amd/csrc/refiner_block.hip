@@ -194,12 +194,8 @@ template <typename T, int KP>
 int launch_rb(const RBParams& p, hipStream_t s) {
   constexpr int KPAD = 32 * KP, RS = KPAD / 8 + 1;
   const size_t smem = (size_t)(NPOS * RS + KPAD * RS + 25 * (KPAD / 8)) * 16 + 3 * KPAD * 4;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(refiner_block_kernel<T, KP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) { set_error("roma_refiner_block: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-    attr_done = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  if (int rc = ensure_dyn_smem(reinterpret_cast<const void*>(refiner_block_kernel<T, KP>), (int)smem, attr_done, "roma_refiner_block")) return rc;
   const int ntile = p.B * p.tiles_x * p.tiles_y;
   const int per_cu = KP == 1 ? 4 : 1;                          // LDS footprint: ~25 KB (KP=1) or ~140 KB (KP=5)
   const int grid = ntile < 256 * per_cu ? ntile : 256 * per_cu;
@@ -277,12 +273,8 @@ template <typename T, int KP>
 int launch_pw(const PWParams& p, hipStream_t s) {
   constexpr int KPAD = 32 * KP, RS = KPAD / 8 + 1, OS = KPAD + 8;
   const size_t smem = (size_t)KPAD * RS * 16 + KPAD * 4 + (size_t)4 * 16 * OS * sizeof(T);
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pointwise_mfma_kernel<T, KP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) { set_error("roma_pointwise_mfma: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-    attr_done = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  if (int rc = ensure_dyn_smem(reinterpret_cast<const void*>(pointwise_mfma_kernel<T, KP>), (int)smem, attr_done, "roma_pointwise_mfma")) return rc;
   const long need = (p.M + 63) / 64;
   const int grid = (int)(need < 512 ? need : 512);             // two persistent workgroups per CU
   hipLaunchKernelGGL((pointwise_mfma_kernel<T, KP>), dim3(grid), dim3(256), smem, s, p);

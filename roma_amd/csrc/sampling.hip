@@ -40,7 +40,7 @@ __device__ __forceinline__ Corner corners(float fx, float fy, int Hs, int Ws) {
 template <typename T>
 __global__ __launch_bounds__(256) void warp_nhwc_kernel(const T* __restrict__ src, const float* __restrict__ flow,
                                                         T* __restrict__ dst, int B, int C, int Hs, int Ws, int H, int W,
-                                                        int src_pitch, int dst_pitch) {
+                                                        int src_pitch, int dst_pitch, int src_shift) {
   constexpr int E16 = ElemTraits<T>::kPer16B;
   const int PK = C / E16;
   const size_t total = (size_t)B * H * W * PK;
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void warp_nhwc_kernel(const T* __restrict__ sr
     const Corner c = corners(fx, fy, Hs, Ws);
     // all four taps are loaded unconditionally from clamped coordinates and masked through their weights: a guarded
     // load would make hipcc branch and wait vmcnt(0) per tap (four serial L2 round trips)
-    const T* base = src + (size_t)b * Hs * Ws * src_pitch + (size_t)k * E16;
+    const T* base = src + (size_t)((b + src_shift) % B) * Hs * Ws * src_pitch + (size_t)k * E16;
     const int xa = min(max(c.x0, 0), Ws - 1), xb = min(max(c.x0 + 1, 0), Ws - 1);
     const int ya = min(max(c.y0, 0), Hs - 1), yb = min(max(c.y0 + 1, 0), Hs - 1);
     const u32x4 v00 = *reinterpret_cast<const u32x4*>(base + ((size_t)ya * Ws + xa) * src_pitch);
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void warp_nhwc_kernel(const T* __restrict__ sr
 template <typename T>
 __global__ __launch_bounds__(256) void warp_generic_kernel(const T* __restrict__ src, const float* __restrict__ flow,
                                                            T* __restrict__ dst, int B, int C, int Hs, int Ws, int H, int W,
-                                                           int src_nhwc, int src_pitch, int dst_nhwc, int dst_pitch) {
+                                                           int src_nhwc, int src_pitch, int dst_nhwc, int dst_pitch, int src_shift) {
   const size_t total = (size_t)B * C * H * W;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     int b, ch, y, x;
@@ -99,9 +99,10 @@ __global__ __launch_bounds__(256) void warp_generic_kernel(const T* __restrict__
     const float fx = flow[((size_t)(b * 2 + 0) * H + y) * W + x];
     const float fy = flow[((size_t)(b * 2 + 1) * H + y) * W + x];
     const Corner c = corners(fx, fy, Hs, Ws);
+    const int bs = (b + src_shift) % B;
     auto at = [&](int yy, int xx) -> float {
-      const size_t o = src_nhwc ? (((size_t)b * Hs + yy) * Ws + xx) * src_pitch + ch
-                                : (((size_t)b * src_pitch + ch) * Hs + yy) * Ws + xx;
+      const size_t o = src_nhwc ? (((size_t)bs * Hs + yy) * Ws + xx) * src_pitch + ch
+                                : (((size_t)bs * src_pitch + ch) * Hs + yy) * Ws + xx;
       return to_f32(src[o]);
     };
     float v = 0.f;
@@ -186,7 +187,8 @@ inline int grid_for(size_t total) {
 using namespace roma;
 
 extern "C" int roma_warp_bilinear(const void* src, const float* flow, void* dst, int B, int C, int Hs, int Ws, int H, int W,
-                                  int dtype, int layout, int src_pitch, int dst_layout, int dst_pitch, void* stream) {
+                                  int dtype, int layout, int src_pitch, int dst_layout, int dst_pitch, int src_batch_shift, void* stream) {
+  ROMA_REQUIRE(src_batch_shift >= 0 && src_batch_shift < (B > 0 ? B : 1), ROMA_E_ARG, "roma_warp_bilinear: src_batch_shift %d outside [0, B)", src_batch_shift);
   ROMA_REQUIRE(src && flow && dst, ROMA_E_ARG, "roma_warp_bilinear: null pointer");
   ROMA_REQUIRE(B > 0 && C > 0 && Hs > 0 && Ws > 0 && H > 0 && W > 0, ROMA_E_SHAPE, "roma_warp_bilinear: bad shape");
   ROMA_REQUIRE(src_pitch >= C && dst_pitch >= C, ROMA_E_SHAPE, "roma_warp_bilinear: pitch smaller than channel count");
@@ -199,10 +201,10 @@ extern "C" int roma_warp_bilinear(const void* src, const float* flow, void* dst,
 #define ROMA_WARP(T)                                                                                                     \
   if (vec)                                                                                                               \
     hipLaunchKernelGGL((warp_nhwc_kernel<T>), dim3(grid_for(total)), dim3(256), 0, s, (const T*)src, flow, (T*)dst, B, C, Hs, \
-                       Ws, H, W, src_pitch, dst_pitch);                                                                  \
+                       Ws, H, W, src_pitch, dst_pitch, src_batch_shift);                                                 \
   else                                                                                                                   \
     hipLaunchKernelGGL((warp_generic_kernel<T>), dim3(grid_for(total)), dim3(256), 0, s, (const T*)src, flow, (T*)dst, B, C, \
-                       Hs, Ws, H, W, layout == ROMA_NHWC, src_pitch, dst_layout == ROMA_NHWC, dst_pitch);
+                       Hs, Ws, H, W, layout == ROMA_NHWC, src_pitch, dst_layout == ROMA_NHWC, dst_pitch, src_batch_shift);
   if (dtype == ROMA_F32) { ROMA_WARP(float) } else if (dtype == ROMA_F16) { ROMA_WARP(half_t) } else { ROMA_WARP(bf16_t) }
 #undef ROMA_WARP
   ROMA_CHECK_LAUNCH();

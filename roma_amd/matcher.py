@@ -130,8 +130,9 @@ class ConvRefiner(nn.Module):
         return torch.empty((B, h, w, self.prepare(dtype)["Dp"]), dtype=dtype, device=device)
 
     @torch.no_grad()
-    def _body(self, x, y, flow, scale_factor, dtype, buf=None):
-        """Everything up to (not including) out_conv: returns the last block's activation (B,h,w,Dp) and the prepared weights."""
+    def _body(self, x, y, flow, scale_factor, dtype, buf=None, batch_shift=0):
+        """Everything up to (not including) out_conv: returns the last block's activation (B,h,w,Dp) and the prepared weights.
+        batch_shift: x[b] is matched against y[(b + batch_shift) % B] (forward_symmetric passes y = x, shift = B/2)."""
         P = self.prepare(dtype)
         B, C, h, w = x.shape
         D, Dp = P["D"], P["Dp"]
@@ -151,10 +152,10 @@ class ConvRefiner(nn.Module):
         if Dp > D:
             buf[..., D:].zero_()
         yy = y.to(dtype)
-        ops.warp_bilinear(yy, flow, out=d[:, C:2 * C])                                        # matcher.py:109
+        ops.warp_bilinear(yy, flow, out=d[:, C:2 * C], batch_shift=batch_shift)               # matcher.py:109
         ops.disp_emb(flow, P["we"], P["be"], 40 / 32 * scale_factor, out=d[:, 2 * C:2 * C + E])  # :111-120
         if r:
-            ops.local_correlation(d[:, :C], yy, r, flow=flow, out=d[:, 2 * C + E:D])           # :121-125
+            ops.local_correlation(d[:, :C], yy, r, flow=flow, out=d[:, 2 * C + E:D], batch_shift=batch_shift)   # :121-125
         M = B * h * w
         cur = buf
         if P["fused"]:
@@ -185,10 +186,10 @@ class ConvRefiner(nn.Module):
         return out[:, :-1], out[:, -1:]
 
     @torch.no_grad()
-    def forward_update(self, x, y, flow, certainty, scale_factor, sx, sy, dtype=None, buf=None):
+    def forward_update(self, x, y, flow, certainty, scale_factor, sx, sy, dtype=None, buf=None, batch_shift=0):
         """The Decoder's use of the refiner (matcher.py:393-402) with out_conv fused into the update kernel:
         flow (B,2,h,w) fp32 contiguous is updated IN PLACE by (sx*dx, sy*dy); returns (flow, certainty + dcert)."""
-        cur, P = self._body(x, y, flow, scale_factor, dtype or self.amp_dtype, buf=buf)
+        cur, P = self._body(x, y, flow, scale_factor, dtype or self.amp_dtype, buf=buf, batch_shift=batch_shift)
         return ops.refiner_head(cur, P["wo"], P["bo"], flow, certainty, sx, sy)
 
 
@@ -236,31 +237,54 @@ class GP(nn.Module):
         ys = y.float().flatten(2).transpose(1, 2).contiguous()
         K_yy = ops.cos_kernel(ys, ys, T=self.K.T, diag_add=self.sigma_noise)
         K_xy = ops.cos_kernel(xs, ys, T=self.K.T)
-        mu = K_xy @ ops.spd_solve(K_yy, self.basis(b, h2, w2, x.device).contiguous())
+        mu = K_xy @ ops.spd_solve(K_yy, self.basis(1, h2, w2, x.device))
         return mu.transpose(1, 2).reshape(b, self.dim, h1, w1)
 
-    def posterior_rows(self, xs, ys, h2, w2, fp64=False):
-        """Token-major variant used by the Decoder: xs, ys (B,N,D) fp32 -> mu (B,N,gp_dim) fp32.
+    def posterior_rows(self, xs, ys, h2, w2, fp64=False, batch_shift=0, out=None, check="now"):
+        """Token-major variant used by the Decoder: xs, ys (B,N,D) rows (any supported dtype, channels-last slices are read in
+        place) -> mu (B,N,gp_dim) fp32.  ys=None with batch_shift=s: y[b] = x[(b+s) % B] (forward_symmetric) — then K_yy of
+        item b is K_xx of item (b+s) % B, so ONE self-kernel matrix and one solve serve both directions.
 
-        fp64=True (the all-fp32 parity mode): K_yy + sigma I has condition number ~1e4 on real features, so ANY fp32
-        evaluation — the reference's own CPU path included — carries ~1e-3 error on mu (measured against an fp64 run:
-        reference fp32 9e-4, fp32 MFMA kernel + blocked solve 1.9e-3, torch.linalg.inv in fp32 on the GPU 2.2e-3).
-        Evaluating kernel matrices and solve in fp64 leaves only the reference's own error in the comparison.  The fast
-        modes use the fp32 MFMA CosKernel + hand-blocked Cholesky below."""
+        fp64=True (diagnostic / the `gp_precision="fp64"` parity mode): K_yy + sigma I has condition number ~1e4 on real
+        features, so ANY fp32 evaluation — the reference's own CPU path included — carries ~1e-3 error on mu (measured
+        against an fp64 run: reference fp32 9e-4, fp32 MFMA kernel + blocked solve 1.9e-3, torch.linalg.inv in fp32 on the
+        GPU 2.2e-3).  Evaluating kernel matrices and solve in fp64 leaves only the reference's own error in the comparison.
+        The product path (fp64=False) is the fp32 MFMA CosKernel + hand-blocked Cholesky."""
+        B, n = xs.shape[0], xs.shape[1]
+        s = batch_shift % B
+        basis = self.basis(1, h2, w2, xs.device)
         if fp64:
-            a, c = xs.double(), ys.double()
+            a = xs.double()
+            c = (a.roll(-s, 0) if s else a) if ys is None else ys.double()
 
             def cosk(u, v):
                 g = torch.einsum("bnd,bmd->bnm", u, v) / (u.norm(dim=-1)[..., None] * v.norm(dim=-1)[:, None] + 1e-6)
                 return ((g - 1.0) / self.K.T).exp()
 
-            n = c.shape[1]
-            Kyy = cosk(c, c) + self.sigma_noise * torch.eye(n, device=c.device, dtype=torch.float64)
-            Z = torch.cholesky_solve(self.basis(xs.shape[0], h2, w2, xs.device).double(), torch.linalg.cholesky(Kyy))
-            return (cosk(a, c) @ Z).float()
+            Kyy = cosk(c, c) + self.sigma_noise * torch.eye(c.shape[1], device=c.device, dtype=torch.float64)
+            Z = torch.cholesky_solve(basis.double().expand(B, -1, -1), torch.linalg.cholesky(Kyy))
+            mu = (cosk(a, c) @ Z).float()
+            if out is not None:
+                out.copy_(mu)
+                return out
+            return mu
+        if ys is None:
+            K_self = ops.cos_kernel(xs, xs, T=self.K.T, diag_add=self.sigma_noise)
+            K_xy = ops.cos_kernel(xs, xs, T=self.K.T, batch_shift=s)
+            Z = ops.spd_solve(K_self, basis, check=check)            # Z[b] belongs to K_yy of item (b - s) % B
+            if out is None:
+                out = torch.empty((B, n, self.dim), dtype=torch.float32, device=xs.device)
+            if s == 0:
+                torch.bmm(K_xy, Z, out=out)
+            else:
+                assert 2 * s == B, "only the half swap of forward_symmetric"
+                torch.bmm(K_xy[:s], Z[s:], out=out[:s])
+                torch.bmm(K_xy[s:], Z[:s], out=out[s:])
+            return out
         K_yy = ops.cos_kernel(ys, ys, T=self.K.T, diag_add=self.sigma_noise)
         K_xy = ops.cos_kernel(xs, ys, T=self.K.T)
-        return K_xy @ ops.spd_solve(K_yy, self.basis(xs.shape[0], h2, w2, xs.device).contiguous())
+        Z = ops.spd_solve(K_yy, basis, check=check)
+        return torch.bmm(K_xy, Z, out=out) if out is not None else torch.bmm(K_xy, Z)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -274,6 +298,10 @@ class Decoder(nn.Module):
         self.scales = list(scales)
         self.refine_init = 4
         self.amp_dtype = amp_dtype
+        # GP arithmetic: "fp32" = the product kernels (fp32-MFMA CosKernel + blocked Cholesky, every amp dtype); "fp64" = torch
+        # fp64 (diagnostic: removes this side's share of the ill-conditioned solve's error from a parity comparison)
+        self.gp_precision = "fp32"
+        self.record = None       # a dict here collects diagnostics of the next forward (scale-16 arg-max indices, GP posterior)
         self._proj = None
 
     def _embedding_decoder_for(self, dtype):
@@ -284,7 +312,11 @@ class Decoder(nn.Module):
         if hit is None or hit[0] != key:
             import copy
             with torch.inference_mode(False), torch.no_grad():
-                hit = (key, copy.deepcopy(self.embedding_decoder).to(dtype).eval())
+                cp = copy.deepcopy(self.embedding_decoder).eval()
+                for m in cp.modules():                      # autocast semantics: 16-bit GEMM weights, fp32 LayerNorm parameters
+                    if isinstance(m, nn.Linear):
+                        m.to(dtype)
+                hit = (key, cp)
             self.__dict__["_embed_cast"] = hit
         return hit[1]
 
@@ -354,24 +386,38 @@ class Decoder(nn.Module):
             refiner = self.conv_refiner[s]
             buf = refiner.new_buffer(b, hs, ws, dtype, device)                               # x lands in its first channels
             x = self.project(s, f1[ins], dtype, out=buf[..., :self.proj[s][0].out_channels])
+            shift = 0
             if swapped_pair:
-                y = torch.cat((x[b // 2:], x[:b // 2]), dim=0)
+                y, shift = x, b // 2                        # y[i] = x[(i + b/2) % b]: the kernels index the swap, nothing is copied
             else:
                 y = self.project(s, f2[ins], dtype)
             if ins in self.embedding_decoder.scales():
-                xs = x.permute(0, 2, 3, 1).reshape(b, hs * ws, -1)
-                ys = y.permute(0, 2, 3, 1).reshape(b, hs * ws, -1)
-                mu = self.gps[s].posterior_rows(xs.float().contiguous(), ys.float().contiguous(), hs, ws,
-                                                fp64=(dtype == torch.float32))                # :377
-                tokens = torch.cat((mu.to(dtype), xs), dim=2)                                 # transformer/__init__.py:35-41
-                # The reference runs this transformer under autocast (transformer/__init__.py:31-32): fp32 parameters, amp-dtype
-                # GEMMs / attention.  Autocast re-casts every weight on every call (0.26 ms of copy kernels per pair), so the
-                # 16-bit modes run a cached amp-dtype copy of the module instead, like the DINOv2 trunk (LayerNorm and
-                # softmax still accumulate in fp32 inside their kernels).
-                rows = self._embedding_decoder_for(dtype).forward_rows(tokens)                # (b, hw, 4097)
+                n = hs * ws
+                xs = x.permute(0, 2, 3, 1).reshape(b, n, -1)                                   # channels-last rows, read in place
+                ys = None if swapped_pair else y.permute(0, 2, 3, 1).reshape(b, n, -1)
+                gp = self.gps[s]
+                C = xs.shape[2]
+                # tokens = cat(gp_posterior [fp32], features) -> fp32 (transformer/__init__.py:33-41): the GP writes mu straight
+                # into the (row-padded) fp32 token buffer
+                npad = n if dtype == torch.float32 else n + (-n % 128)
+                tokens = torch.empty((b, npad, gp.dim + C), dtype=torch.float32, device=device)
+                if npad > n:
+                    tokens[:, n:].zero_()
+                tokens[:, :n, gp.dim:].copy_(xs)
+                gp.posterior_rows(xs, ys, hs, ws, fp64=(self.gp_precision == "fp64"), batch_shift=shift,
+                                  out=tokens[:, :n, :gp.dim], check="defer")                   # :377
+                # The reference runs this transformer under autocast (transformer/__init__.py:31-32): fp32 token / residual
+                # stream and LayerNorm, amp-dtype GEMMs / attention / logits.  Autocast re-casts every weight on every call
+                # (0.26 ms of copy kernels per pair), so the 16-bit modes run a cached copy of the module whose Linear weights
+                # are in the amp dtype; the stream stays fp32 (ops.add_layernorm fuses residual add + LayerNorm + cast).
+                rows = self._embedding_decoder_for(dtype).forward_rows(tokens, n_valid=n, owned=True)   # (b, hw, 4097)
                 flow, certainty = ops.cls_rows_to_flow(rows, b, hs, ws)                       # :378-385
+                if self.record is not None and not upsample:
+                    self.record["argmax16"] = rows[..., :-1].float().argmax(dim=-1).cpu()     # (b, hw) anchor index (utils.py:316)
+                    self.record["mu16"] = tokens[:, :n, :gp.dim].detach().clone()
             flow, certainty = refiner.forward_update(                                         # :393-402
-                x, y, flow, certainty, scale_factor, ins / (self.refine_init * w), ins / (self.refine_init * h), dtype=dtype, buf=buf)
+                x, y, flow, certainty, scale_factor, ins / (self.refine_init * w), ins / (self.refine_init * h), dtype=dtype, buf=buf,
+                batch_shift=shift)
             corresps[ins].update({"certainty": certainty, "flow": flow})
             if s != "1":
                 flow = ops.interp_bilinear(flow, sizes[ins // 2])                             # :408-417
@@ -441,21 +487,29 @@ class RegressionMatcher(nn.Module):
                             wait_events=batch.get("wait_events"), **kw)
 
     # -- sampling --------------------------------------------------------------------------------
-    def sample(self, matches, certainty, num=10000):
-        """matcher.py:468-495: certainty-thresholded multinomial draw, then KDE-balanced re-draw (fused HIP KDE)."""
-        if "threshold" in self.sample_mode:
-            certainty = certainty.clone()
-            certainty[certainty > self.sample_thresh] = 1
+    def sample(self, matches, certainty, num=10000, seed=None):
+        """matcher.py:468-495: certainty-thresholded draw of 4*num matches without replacement, KDE-balanced re-draw of num.
+
+        Both of the reference's `torch.multinomial(w, k, replacement=False)` calls are exponential races (key = w / Exp(1),
+        keep the k largest — also what ATen does internally); here the threshold, a counter-based uniform and the key are one
+        kernel (ops.race_keys) and the selection is a top-k.  `seed` makes the draw a pure function of (inputs, seed) that the
+        CPU oracle reproduces (oracle.sample_seeded); seed=None takes one from torch's CPU generator (torch.manual_seed governs
+        it, no device sync).  Matches are returned in draw order."""
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        thresh = self.sample_thresh if "threshold" in self.sample_mode else -1.0
         matches, certainty = matches.reshape(-1, 4), certainty.reshape(-1)
         expansion = 4 if "balanced" in self.sample_mode else 1
-        good = torch.multinomial(certainty, num_samples=min(expansion * num, len(certainty)), replacement=False)
+        good = torch.topk(ops.race_keys(certainty, thresh, seed), min(expansion * num, len(certainty))).indices
         good_matches, good_certainty = matches[good], certainty[good]
+        if thresh >= 0:
+            good_certainty = torch.where(good_certainty > thresh, torch.ones_like(good_certainty), good_certainty)   # :474-477
         if "balanced" not in self.sample_mode:
             return good_matches, good_certainty
-        density = ops.kde(good_matches, std=0.1)
+        density = ops.kde(good_matches, std=0.1)                                              # fp16, like the reference (:489)
         p = 1 / (density + 1)
         p[density < 10] = 1e-7
-        bal = torch.multinomial(p.float(), num_samples=min(num, len(good_certainty)), replacement=False)
+        bal = torch.topk(ops.race_keys(p, -1.0, seed + 1), min(num, len(good_certainty))).indices
         return good_matches[bal], good_certainty[bal]
 
     # -- coordinates -----------------------------------------------------------------------------
@@ -536,7 +590,9 @@ class RegressionMatcher(nn.Module):
                 batch["pyramid"] = hi_pyr
             corresps = (self.forward_symmetric(batch, upsample=True, scale_factor=scale_factor) if symmetric
                         else self.forward(batch, batched=True, upsample=True, scale_factor=scale_factor))
-        return ops.match_finalize(corresps[1]["flow"], corresps[1]["certainty"], cert16, symmetric=symmetric)
+        out = ops.match_finalize(corresps[1]["flow"], corresps[1]["certainty"], cert16, symmetric=symmetric)
+        ops.raise_pending()          # the GP solve's SPD check, deferred so that the pipeline has no host sync in the middle
+        return out
 
     @torch.inference_mode()
     def match(self, im_A_input, im_B_input, *args, batched=False, device=None, im_A_hi=None, im_B_hi=None):

@@ -76,10 +76,22 @@ TIMER = KernelTimer()
 
 
 def _need_gpu(*ts):
+    """Every tensor lives on ONE ROCm device, and that device is the current one (the launch goes to torch's current
+    stream, which belongs to the current device)."""
+    dev = None
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise RuntimeError("roma_amd kernels run on an MI355X (ROCm device tensors) only; got a "
                                f"{t.device} tensor and there is no CPU fallback")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"roma_amd kernel arguments live on different devices ({dev} and {t.device})")
+    if dev is not None and dev.index != torch.cuda.current_device():
+        raise RuntimeError(f"roma_amd kernel arguments live on {dev} but the current device is cuda:{torch.cuda.current_device()}; "
+                           "wrap the call in `with torch.cuda.device(t.device):`")
 
 
 def _stream():
@@ -117,9 +129,11 @@ def nhwc_empty(B, C, H, W, dtype, device, pitch=None):
     return buf[..., :C].permute(0, 3, 1, 2)
 
 
-def local_correlation(feature0, feature1, local_radius, padding_mode="zeros", flow=None, sample_mode="bilinear", out=None):
+def local_correlation(feature0, feature1, local_radius, padding_mode="zeros", flow=None, sample_mode="bilinear", out=None,
+                      batch_shift=0):
     """romatch/utils/local_correlation.py:4-48.  Returns (B,(2r+1)^2,h,w) in feature0's dtype and memory format
-    (or fills `out`, e.g. a channel slice of the refiner's channels-last concat buffer)."""
+    (or fills `out`, e.g. a channel slice of the refiner's channels-last concat buffer).  batch_shift: feature0[b] meets
+    feature1[(b + batch_shift) % B] (forward_symmetric passes the same map twice with batch_shift = B/2)."""
     if padding_mode != "zeros" or sample_mode != "bilinear":
         raise NotImplementedError("only padding_mode='zeros', sample_mode='bilinear' (the modes RoMa uses)")
     _need_gpu(feature0, feature1, flow, out)
@@ -148,12 +162,13 @@ def local_correlation(feature0, feature1, local_radius, padding_mode="zeros", fl
     nbytes = 2 * B * C * H * W * es + B * 2 * H * W * 4 + B * K * H * W * es
     TIMER.wrap("local_corr", nbytes, f"C{C}_h{H}x{W}_r{r}",
                lambda: check(_lib.load().roma_local_corr(_p(f0), _p(f1), _p(flow), _p(out), B, C, H, W, r, _dt(f0), l0, p0, p1,
-                                                         lo, po, _stream()), "roma_local_corr"))
+                                                         lo, po, int(batch_shift) % B, _stream()), "roma_local_corr"))
     return out
 
 
-def warp_bilinear(src, flow, out=None):
-    """F.grid_sample(src, flow.permute(0,2,3,1), mode='bilinear', align_corners=False) — matcher.py:109."""
+def warp_bilinear(src, flow, out=None, batch_shift=0):
+    """F.grid_sample(src, flow.permute(0,2,3,1), mode='bilinear', align_corners=False) — matcher.py:109.
+    batch_shift: output item b samples src[(b + batch_shift) % B]."""
     _need_gpu(src, flow, out)
     B, C, Hs, Ws = src.shape
     _, _, H, W = flow.shape
@@ -164,7 +179,7 @@ def warp_bilinear(src, flow, out=None):
     lo, po, o = feat_layout(out)
     if o is not out:
         raise ValueError("out must be contiguous or channels-last")
-    check(_lib.load().roma_warp_bilinear(_p(s), _p(flow), _p(out), B, C, Hs, Ws, H, W, _dt(s), ls, ps, lo, po, _stream()),
+    check(_lib.load().roma_warp_bilinear(_p(s), _p(flow), _p(out), B, C, Hs, Ws, H, W, _dt(s), ls, ps, lo, po, int(batch_shift) % B, _stream()),
           "roma_warp_bilinear")
     return out
 
@@ -238,20 +253,68 @@ def cls_rows_to_flow(rows, B, H, W):
     return flow, cert
 
 
-def cos_kernel(x, y, T=0.2, eps=1e-6, diag_add=0.0):
-    """CosKernel.__call__ — matcher.py:154-163.  x (B,N,D), y (B,M,D) -> (B,N,M) fp32, on the fp32 MFMA."""
+def _rows(t):
+    """(B,N,D) rows with unit channel stride and a common row pitch (a channels-last feature slice qualifies): returns
+    (tensor, pitch) without copying when possible."""
+    B, N, D = t.shape
+    es = t.element_size()
+    if t.stride(2) == 1 and t.stride(0) == N * t.stride(1) and t.stride(1) >= D and (t.stride(1) * es) % 16 == 0 \
+            and t.data_ptr() % 16 == 0 and t.dtype in _DT:
+        return t, t.stride(1)
+    t = (t if t.dtype in _DT else t.float()).contiguous()
+    return t, D
+
+
+def cos_kernel(x, y, T=0.2, eps=1e-6, diag_add=0.0, batch_shift=0):
+    """CosKernel.__call__ — matcher.py:154-163.  x (B,N,D), y (B,M,D) -> (B,N,M) fp32, on the fp32 MFMA.  16-bit rows are
+    widened exactly in the kernel (= the reference's `.float()`, matcher.py:254); x[b] meets y[(b + batch_shift) % B]."""
     _need_gpu(x, y)
-    x = x.float().contiguous()
-    y = y.float().contiguous()
+    if x.dtype != y.dtype:
+        x, y = x.float(), y.float()
+    x, xp = _rows(x)
+    y, yp = _rows(y)
     B, N, D = x.shape
     M = y.shape[1]
     K = torch.empty((B, N, M), dtype=torch.float32, device=x.device)
-    check(_lib.load().roma_cos_kernel(_p(x), _p(y), _p(K), B, N, M, D, float(T), float(eps), float(diag_add), _stream()),
-          "roma_cos_kernel")
+    check(_lib.load().roma_cos_kernel(_p(x), _p(y), _p(K), B, N, M, D, _dt(x), xp, yp, int(batch_shift) % B, float(T), float(eps),
+                                      float(diag_add), _stream()), "roma_cos_kernel")
     return K
 
 
-def spd_solve(K, F, nb=64):
+class _PendingSpdCheck:
+    """`info` of one spd_solve on its way to pinned host memory; examined by raise_pending() once the copy has landed."""
+
+    def __init__(self, info):
+        self.host = torch.empty(info.shape, dtype=info.dtype, pin_memory=True)
+        self.host.copy_(info, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+
+    def result(self):
+        self.event.synchronize()
+        return self.host.tolist()
+
+
+_PENDING = []
+
+
+def _raise_if_not_spd(bad):
+    if any(bad):
+        b = next(i for i, v in enumerate(bad) if v)
+        raise _lib.RomaHipError(f"spd_solve: matrix {b} of the batch is not positive definite (block step {(bad[b] - 1) // 64}, pivot "
+                                f"{(bad[b] - 1) % 64} is <= 0 or NaN) — non-finite or degenerate features?  The reference's "
+                                f"torch.linalg.inv raises here too (matcher.py:261).")
+
+
+def raise_pending():
+    """Examine the deferred spd_solve checks (RegressionMatcher.match_tensors calls this before it returns: by then the
+    factorisation finished long ago, so the wait is free)."""
+    todo, _PENDING[:] = list(_PENDING), []
+    for chk in todo:
+        _raise_if_not_spd(chk.result())
+
+
+def spd_solve(K, F, nb=64, check="now"):
     """Solve K X = F for a batch of SPD matrices by a hand-blocked Cholesky: K (B,n,n) fp32, F (B,n,m) fp32.  Replaces
     `inv(K) @ F` of GP.forward (matcher.py:259-263).
 
@@ -261,13 +324,38 @@ def spd_solve(K, F, nb=64):
          the block's share of the forward substitution at once);
       3. ONE GEMM  A[below, right] -= R_left^T @ R  (trailing update of K and of the right-hand sides together).
     The forward substitution therefore never runs as a separate sweep; the backward one takes two GEMMs per block.
-    125 launches for n = 1600 instead of the 250 of the textbook three-sweep form."""
+    125 launches for n = 1600 instead of the 250 of the textbook three-sweep form.
+
+    A non-positive or NaN pivot (K not SPD: non-finite / degenerate features) is recorded by the kernel, which clamps it
+    and carries on; check="now" reads that record back and raises like the reference's torch.linalg.inv does;
+    check="defer" queues an asynchronous copy of it and raise_pending() raises later (no host sync inside the pipeline);
+    check=None skips it.
+
+    PYTORCH_TUNABLEOP_ENABLED=1: TunableOp's candidate sweep returned hipErrorInvalidValue for the in-place strided
+    trailing update of an earlier build (gpurun_out/bench_tune.err, round 1); the GEMMs of this routine therefore always
+    run with TunableOp switched off (restored afterwards)."""
     _need_gpu(K, F)
     assert K.dtype == torch.float32 and F.dtype == torch.float32
+    tun = torch.cuda.tunable.is_enabled()
+    if tun:
+        torch.cuda.tunable.enable(False)
+    try:
+        X, info = _spd_solve(K, F, nb)
+    finally:
+        if tun:
+            torch.cuda.tunable.enable(True)
+    if check == "now":
+        _raise_if_not_spd(info.tolist())
+    elif check == "defer":
+        _PENDING.append(_PendingSpdCheck(info))
+    return X
+
+
+def _spd_solve(K, F, nb):
     B, n, _ = K.shape
     m = F.shape[2]
     lib = _lib.load()
-    A = torch.cat((K, F), dim=2)                                  # (B, n, n+m)
+    A = torch.cat((K, F.expand(B, -1, -1)), dim=2)                # (B, n, n+m)
     steps = [(j, min(j + nb, n)) for j in range(0, n, nb)]
     W = torch.empty((B, len(steps), nb, nb), dtype=torch.float32, device=K.device)
     info = torch.zeros((B,), dtype=torch.int32, device=K.device)
@@ -275,7 +363,7 @@ def spd_solve(K, F, nb=64):
     for s, (j, e) in enumerate(steps):
         w = e - j
         check(lib.roma_chol_diag_block(A[:, j:e, j:e].data_ptr(), A.stride(1), A.stride(0), W[:, s].data_ptr(), nb, W.stride(0), w, B,
-                                       info.data_ptr(), _stream()), "roma_chol_diag_block")
+                                       info.data_ptr(), 64 * s, _stream()), "roma_chol_diag_block")
         r = torch.bmm(W[:, s, :w, :w], A[:, j:e, e:])             # (B, w, (n-e)+m) = [L[e:, j:e]^T | Y[j:e]]
         R.append(r)
         if e < n:
@@ -289,7 +377,7 @@ def spd_solve(K, F, nb=64):
         if e < n:
             t = torch.baddbmm(t, r[:, :, :n - e], X[:, e:], alpha=-1.0)
         torch.bmm(W[:, s, :w, :w].transpose(1, 2), t, out=X[:, j:e])
-    return X
+    return X, info
 
 
 def match_finalize(flow, certainty, cert16, symmetric=True):
@@ -312,16 +400,29 @@ def match_finalize(flow, certainty, cert16, symmetric=True):
 
 
 def kde(x, std=0.1, half=True, down=None):
-    """romatch/utils/kde.py:4-12.  half=True rounds the coordinates to fp16 first (as the reference does) and returns
-    fp16; the pairwise sums themselves are fp32 (the reference's fp16 cdist is NOT reproduced bit for bit)."""
+    """romatch/utils/kde.py:4-12.  half=True (the reference's default): the coordinates are rounded to fp16 and every term
+    goes through the rounding points of the reference's fp16 evaluation (torch.cdist's matmul route in fp16, then fp16
+    `** 2`, `/`, `exp`), summed in fp32, result fp16 — the reference's own fp16 noise (up to ~20 % per term) is part of
+    what sample()'s `density < 10` cut sees, so it is reproduced rather than removed.  half=False: fp32 throughout."""
     _need_gpu(x)
     if x.dim() != 2 or x.shape[1] != 4:
         raise ValueError("kde expects (N,4) matches")
     xs = (x.half() if half else x).float().contiguous()
     N = xs.shape[0]
     dens = torch.empty((N,), dtype=torch.float32, device=x.device)
-    check(_lib.load().roma_kde_density(_p(xs), _p(dens), N, int(down or 1), float(std), _stream()), "roma_kde_density")
+    check(_lib.load().roma_kde_density(_p(xs), _p(dens), N, int(down or 1), float(std), 1 if half else 0, _stream()), "roma_kde_density")
     return dens.half() if half else dens
+
+
+def race_keys(p, thresh=-1.0, seed=0):
+    """Exponential-race keys of sampling without replacement (matcher.py:474-493): key_i = w_i / E_i, w_i = 1 where
+    p_i > thresh >= 0 else p_i, E_i ~ Exp(1) from a counter hash of (seed, i).  topk(keys, k) is a draw of k items without
+    replacement with probabilities proportional to w."""
+    _need_gpu(p)
+    p = p.reshape(-1).float().contiguous()
+    keys = torch.empty_like(p)
+    check(_lib.load().roma_race_keys(_p(p), _p(keys), p.numel(), float(thresh), int(seed) & 0xFFFFFFFF, _stream()), "roma_race_keys")
+    return keys
 
 
 def dwconv5x5_bn_relu(x, w25, scale, shift, out=None):
@@ -440,6 +541,21 @@ def pointwise_small(x_rows, wt, bias, out=None):
     return out
 
 
+def add_layernorm(x, y, ln_weight, ln_bias, eps, out_dtype, ls=None):
+    """x <- x + ls*y (in place, x's dtype; y None: no add); returns LayerNorm(x)*w+b cast to out_dtype (ln_weight None: just
+    the cast).  x (..., C) contiguous rows; the seam between two transformer half-blocks (transformer/layers/block.py:87-107)."""
+    _need_gpu(x, y, ln_weight, ln_bias, ls)
+    C = x.shape[-1]
+    assert x.is_contiguous() and (y is None or (y.is_contiguous() and y.shape == x.shape))
+    rows = x.numel() // C
+    out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    for t in (ln_weight, ln_bias, ls):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.numel() == C)
+    check(_lib.load().roma_add_layernorm(_p(x), _dt(x), C, _p(y), _dt(y) if y is not None else 0, C, _p(ls), _p(ln_weight), _p(ln_bias),
+                                         _p(out), _DT[out_dtype], C, rows, C, float(eps), _stream()), "roma_add_layernorm")
+    return out
+
+
 def tiny_corr_posembed(f0, f1, exact=False):
     """TinyRoMa.corr_volume + pos_embed fused — tiny.py:241-254,178-203.  f0 (B,C,H0,W0), f1 (B,C,H1,W1) -> (B,2,H0,W0)."""
     _need_gpu(f0, f1)
@@ -448,6 +564,8 @@ def tiny_corr_posembed(f0, f1, exact=False):
     a = f0.float().permute(0, 2, 3, 1).contiguous()
     b = f1.float().permute(0, 2, 3, 1).contiguous()
     out = torch.empty((B, 2, H0, W0), dtype=torch.float32, device=f0.device)
-    check(_lib.load().roma_tiny_corr_posembed(_p(a), _p(b), _p(out), B, C, H0, W0, H1, W1, 1 if exact else 0, _stream()),
-          "roma_tiny_corr_posembed")
+    # MFMA-bound: the "bytes" slot of the timer carries the algorithmic FLOPs 2 * N0 * N1 * C per item
+    TIMER.wrap("tiny_corr", 2.0 * B * H0 * W0 * H1 * W1 * C, f"C{C}_{H0}x{W0}",
+               lambda: check(_lib.load().roma_tiny_corr_posembed(_p(a), _p(b), _p(out), B, C, H0, W0, H1, W1, 1 if exact else 0, _stream()),
+                             "roma_tiny_corr_posembed"))
     return out

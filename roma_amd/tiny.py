@@ -140,18 +140,41 @@ class TinyRoMa(nn.Module):
         warp, cert = torch.cat((grid, flow), dim=-1), cert[:, 0].sigmoid()
         return (warp, cert) if batched else (warp[0], cert[0])
 
-    def sample(self, matches, certainty, num=5_000):                                           # tiny.py:297-327
-        if "threshold" in self.sample_mode:
-            certainty = certainty.clone()
-            certainty[certainty > self.sample_thresh] = 1
+    def sample(self, matches, certainty, num=5_000, seed=None):                               # tiny.py:297-327
+        """Same exponential-race formulation as RegressionMatcher.sample (roma_amd/matcher.py)."""
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        thresh = self.sample_thresh if "threshold" in self.sample_mode else -1.0
         matches, certainty = matches.reshape(-1, 4), certainty.reshape(-1)
         expansion = 4 if "balanced" in self.sample_mode else 1
-        good = torch.multinomial(certainty, num_samples=min(expansion * num, len(certainty)), replacement=False)
+        good = torch.topk(ops.race_keys(certainty, thresh, seed), min(expansion * num, len(certainty))).indices
         gm, gc = matches[good], certainty[good]
+        if thresh >= 0:
+            gc = torch.where(gc > thresh, torch.ones_like(gc), gc)
         if "balanced" not in self.sample_mode:
             return gm, gc
         density = ops.kde(gm, std=0.1, half=True, down=1)
         p = 1 / (density + 1)
         p[density < 10] = 1e-7
-        bal = torch.multinomial(p.float(), num_samples=min(num, len(gc)), replacement=False)
+        bal = torch.topk(ops.race_keys(p, -1.0, seed + 1), min(num, len(gc))).indices
         return gm[bal], gc[bal]
+
+
+class XFeatBackbone(nn.Module):
+    """The XFeat backbone TOPOLOGY ("XFeat: Accelerated Features for Lightweight Image Matching", CVPR 2024) with the
+    attributes TinyRoMa.forward_single touches (tiny.py:146-159): 24-channel stride-4 and 64-channel stride-8 outputs.  The
+    reference fetches the network from a hub repository (model_zoo/__init__.py:22-26) that is absent offline; its layer
+    plan is restated, widened to 32 channels, at experiments/model_tiny1.py:34-117 — this is that plan at the published
+    widths.  Used with synthetic weights by bench.py's `tiny` workload; parity of the backbone itself is unpinned."""
+
+    def __init__(self):
+        super().__init__()
+        L = BasicLayer
+        self.norm = nn.InstanceNorm2d(1)
+        self.skip1 = nn.Sequential(nn.AvgPool2d(4, stride=4), nn.Conv2d(1, 24, 1, stride=1, padding=0))
+        self.block1 = nn.Sequential(L(1, 4, stride=1), L(4, 8, stride=2), L(8, 8, stride=1), L(8, 24, stride=2))
+        self.block2 = nn.Sequential(L(24, 24, stride=1), L(24, 24, stride=1))
+        self.block3 = nn.Sequential(L(24, 64, stride=2), L(64, 64, stride=1), L(64, 64, 1, padding=0))
+        self.block4 = nn.Sequential(L(64, 64, stride=2), L(64, 64, stride=1), L(64, 64, stride=1))
+        self.block5 = nn.Sequential(L(64, 128, stride=2), L(128, 128, stride=1), L(128, 128, stride=1), L(128, 64, 1, padding=0))
+        self.block_fusion = nn.Sequential(L(64, 64, stride=1), L(64, 64, stride=1), nn.Conv2d(64, 64, 1, padding=0))

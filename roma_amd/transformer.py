@@ -71,6 +71,44 @@ class Block(nn.Module):
         return self._residual(x, self.mlp(self.norm2(x)), self.ls2)
 
 
+def _seam_params(blocks, final_norm=None):
+    """fp32 contiguous copies of what the fused add + LayerNorm seams read (LayerNorm affine, LayerScale gammas), cached on
+    the module list owner; the modules passed here are frozen inference copies."""
+    out = []
+    for blk in blocks:
+        f = lambda t: t.detach().float().contiguous()
+        out.append(dict(n1=(f(blk.norm1.weight), f(blk.norm1.bias), blk.norm1.eps), n2=(f(blk.norm2.weight), f(blk.norm2.bias), blk.norm2.eps),
+                        ls1=f(blk.ls1.gamma) if isinstance(blk.ls1, LayerScale) else None,
+                        ls2=f(blk.ls2.gamma) if isinstance(blk.ls2, LayerScale) else None))
+    fin = None
+    if final_norm is not None:
+        fin = (final_norm.weight.detach().float().contiguous(), final_norm.bias.detach().float().contiguous(), final_norm.eps)
+    return out, fin
+
+
+def run_blocks_fused(blocks, params, x, n_valid, compute_dtype, final=None):
+    """A stack of pre-LN blocks (layers/block.py:87-107) with every `residual add (+ LayerScale)` fused with the NEXT
+    LayerNorm into one kernel (ops.add_layernorm): x is the residual stream — fp32 for the decoder transformer (what autocast
+    gives the reference, transformer/__init__.py:30-46), the amp dtype for the DINOv2 trunk (the reference casts that module
+    itself, encoders.py:102-103) — and is updated in place; attention and MLP run on `compute_dtype` tensors.  Returns
+    final LayerNorm(x) when `final` = (weight, bias, eps), else x cast to compute_dtype (the cast in front of `to_out`)."""
+    from . import ops
+    h = ops.add_layernorm(x, None, *params[0]["n1"], compute_dtype)
+    last = len(blocks) - 1
+    for i, blk in enumerate(blocks):
+        p = params[i]
+        a = blk.attn(h, n_valid)
+        h = ops.add_layernorm(x, a, *p["n2"], compute_dtype, ls=p["ls1"])
+        m = blk.mlp(h)
+        if i < last:
+            h = ops.add_layernorm(x, m, *params[i + 1]["n1"], compute_dtype, ls=p["ls2"])
+        elif final is not None:
+            h = ops.add_layernorm(x, m, *final, compute_dtype, ls=p["ls2"])
+        else:
+            h = ops.add_layernorm(x, m, None, None, 0.0, compute_dtype, ls=p["ls2"])
+    return h
+
+
 class TransformerDecoder(nn.Module):
     """Returns the token-major logit rows (B, H*W, out_dim) — the (B,out_dim,H,W) permute of the reference
     (transformer/__init__.py:44) is folded into the consumer kernel's strides."""
@@ -85,16 +123,27 @@ class TransformerDecoder(nn.Module):
     def scales(self):
         return self._scales.copy()
 
-    def forward_rows(self, tokens):
-        n = tokens.shape[1]
-        if tokens.dtype == torch.float32 or n % 128 == 0:
-            return self.to_out(self.blocks(tokens))
-        # 16-bit mode: row-pad the sequence to the attention / GEMM tile (see DinoViT.patch_tokens); padding rows are
-        # queries only and are dropped from the returned view
-        t = F.pad(tokens, (0, 0, 0, 128 - n % 128))
-        for blk in self.blocks:
-            t = blk(t, n)
-        return self.to_out(t)[:, :n]
+    def forward_rows(self, tokens, n_valid=None, owned=False):
+        """tokens (B, N, hidden) -> logit rows (B, N, out_dim).  When the module's GEMM weights are 16-bit (the cached
+        amp-dtype copy the Decoder makes) the arithmetic is the reference's autocast (transformer/__init__.py:30-46): fp32
+        token / residual stream and LayerNorm, 16-bit GEMMs and attention, 16-bit logits.
+        n_valid: the caller already row-padded the sequence (rows >= n_valid are padding); owned=True: `tokens` is a fresh
+        fp32 contiguous buffer this call may update in place."""
+        n = tokens.shape[1] if n_valid is None else n_valid
+        wdt = self.to_out.weight.dtype
+        if wdt == torch.float32:
+            return self.to_out(self.blocks(tokens[:, :n].float()))
+        # row-pad the sequence to the attention / GEMM tile (see DinoViT.patch_tokens); padding rows are queries only and are
+        # dropped from the returned view
+        if owned and tokens.dtype == torch.float32 and tokens.is_contiguous() and tokens.shape[1] % 128 == 0:
+            t = tokens
+        else:
+            t = F.pad(tokens[:, :n].float(), (0, 0, 0, -n % 128)) if n % 128 else tokens.float().clone()
+        cache = self.__dict__.get("_seams")
+        if cache is None:
+            cache = self.__dict__["_seams"] = _seam_params(self.blocks)
+        z = run_blocks_fused(list(self.blocks), cache[0], t, n if t.shape[1] != n else None, wdt)
+        return self.to_out(z)[:, :n]
 
 
 class PatchEmbed(nn.Module):
@@ -156,6 +205,13 @@ class DinoViT(nn.Module):
             # token, and the GEMMs' tile count does not change (3202 -> 3328 rows = 13 tiles of 256 either way).
             n_valid = n
             t = F.pad(t, (0, 0, 0, 128 - n % 128))
-        for blk in self.blocks:
-            t = blk(t, n_valid)
-        return self.norm(t[:, 1:n])
+        if t.dtype == torch.float32 or not t.is_cuda:
+            for blk in self.blocks:
+                t = blk(t, n_valid)
+            return self.norm(t[:, 1:n])
+        # 16-bit modes: residual add + LayerScale + next LayerNorm in one kernel per seam (49 launches instead of 97)
+        cache = self.__dict__.get("_seams")
+        if cache is None:
+            cache = self.__dict__["_seams"] = _seam_params(self.blocks, self.norm)
+        t = t.contiguous()
+        return run_blocks_fused(list(self.blocks), cache[0], t, n_valid, t.dtype, final=cache[1])[:, 1:n]

@@ -26,16 +26,20 @@ def test_library_exports_every_declared_symbol():
 
 def test_version_and_error_string():
     lib = _lib.load()
-    assert lib.roma_abi_version() == 1
+    assert lib.roma_abi_version() == 2
     assert isinstance(lib.roma_last_error(), bytes)
 
 
 def test_argument_validation_needs_no_gpu():
     lib = _lib.load()
-    rc = lib.roma_local_corr(None, None, None, None, 1, 8, 4, 4, 2, 0, 0, 8, 8, 0, 25, None)
+    rc = lib.roma_local_corr(None, None, None, None, 1, 8, 4, 4, 2, 0, 0, 8, 8, 0, 25, 0, None)
     assert rc == -1 and b"null pointer" in lib.roma_last_error()
-    rc = lib.roma_kde_density(None, None, 0, 1, 0.1, None)
+    rc = lib.roma_kde_density(None, None, 0, 1, 0.1, 0, None)
     assert rc < 0
+    rc = lib.roma_add_layernorm(None, 0, 8, None, 0, 8, None, None, None, None, 0, 8, 1, 8, 1e-5, None)
+    assert rc == -1 and b"null pointer" in lib.roma_last_error()
+    rc = lib.roma_race_keys(None, None, 4, 0.05, 1, None)
+    assert rc == -1
 
 
 def test_ops_refuse_cpu_tensors():

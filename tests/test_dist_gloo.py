@@ -67,3 +67,35 @@ def test_single_process_is_identity():
     from roma_amd.dist import match_sharded
     w, c = match_sharded(_fake_match, [0, 1, 2])
     assert w.shape[0] == 3 and float(w[2, 0, 0, 0]) == 2.0
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no torchrun environment must start 2 ranks itself (as a child process), run the
+    barrier / max-over-ranks / ordered-gather plumbing and print ONE JSON line with n_gpus = 2.  ROMA_BENCH_STUB=1 replaces
+    the GPU step by a stand-in so that this runs on the CPU box over gloo."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(ROMA_BENCH_STUB="1", ROMA_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--pairs", "2"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["stub"] is True
+    assert d["config"]["gather_order_ok"] is True and d["value"] > 0
+
+
+def test_bench_refuses_mismatched_world():
+    """Under an external launcher bench.py is a rank: --gpus must equal WORLD_SIZE (a silent N=1 measurement is the failure
+    mode this guards against)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ROMA_BENCH_STUB="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)

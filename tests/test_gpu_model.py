@@ -62,13 +62,17 @@ def test_gp_fast_path_vs_fp64_on_real_features(full_model):
     exact = gp.posterior_rows(xs, ys, 40, 40, fp64=True)
     err = float((fast - exact).abs().max())
     print(f"GP fast (fp32 MFMA + blocked Cholesky) vs fp64: max|d| = {err:.2e}, |mu| max = {float(exact.abs().max()):.2f}")
-    assert err < 1e-2
+    assert err < 6e-3                                            # measured 1.9e-3 (x3); the reference's own fp32 path: 9e-4
+    # the swapped-pair form the Decoder uses (one self-kernel matrix + one solve for both directions, rows read in place)
+    sw = gp.posterior_rows(xs, None, 40, 40, batch_shift=1)
+    assert float((sw - fast).abs().max()) < 1e-4
 
 
 def test_decoder_both_modes_golden():
     g = H.golden("decoder")
     dec = H.load_recipe_weights(H.build_reduced_decoder(_M()), "dec.", gains=cases.DEC_GAINS).to(DEV)
     dec.amp_dtype = torch.float32
+    assert dec.gp_precision == "fp32"                             # the product GP kernels, not the fp64 diagnostic
     f1, f2 = cases.decoder_pyramids("coarse", 2, 112, upsample=False)
     c = dec({s: H.T(v, DEV) for s, v in f1.items()}, {s: H.T(v, DEV) for s, v in f2.items()})
     for s in (16, 8, 4, 2, 1):
@@ -95,29 +99,42 @@ def full_model():
     return m.to(DEV).eval()
 
 
-def _set_dtype(m, dt):
+def _set_dtype(m, dt, gp="fp32"):
     m.encoder.amp_dtype = dt
     m.decoder.amp_dtype = dt
+    m.decoder.gp_precision = gp
+    m.decoder.record = None
     for r in m.decoder.conv_refiner.values():
         r.amp_dtype = dt
 
 
-def test_end_to_end_reduced_fp32_vs_reference_golden(full_model):
+# Parity bounds of the fp32 mode against the reference's own outputs, per GP arithmetic:
+#   "fp32" = the product kernels (fp32-MFMA CosKernel + blocked Cholesky) — what every mode, including the timed fp16 one, runs;
+#   "fp64" = GP in torch fp64 (diagnostic): K_yy + sigma I has condition number ~1e4 on real features, so two DIFFERENT fp32
+#            evaluations of mu differ by ~1e-3 (the reference's own fp32 CPU path is 9e-4 from an fp64 run); fp64 on this side
+#            leaves only the reference's share in the comparison.
+# Bounds are (measured on MI355X) x 3, capped by the 1e-3 bar of BASELINE.json where the measurement allows it.
+GP_MODES = ["fp32", "fp64"]
+
+
+@pytest.mark.parametrize("gp", GP_MODES)
+def test_end_to_end_reduced_fp32_vs_reference_golden(full_model, gp):
     """The shipped architecture (ViT-L/14 + VGG19-BN + full decoder), sacre_coeur pair, 112->168, fp32 mode."""
     g = H.golden("e2e_112")
-    _set_dtype(full_model, torch.float32)
+    _set_dtype(full_model, torch.float32, gp)
     warp, cert = full_model.match(H.asset("sacre_coeur_A.jpg"), H.asset("sacre_coeur_B.jpg"), device=DEV)
     assert warp.shape == (168, 336, 4) and cert.shape == (168, 336) and warp.dtype == torch.float32
     dw = (warp.cpu() - H.T(g["r112_warp"])).abs()
     dc = (cert.cpu() - H.T(g["r112_cert"])).abs()
     frac = float((dw > 1e-3).float().mean())
-    print(f"fp32 e2e: warp max {float(dw.max()):.2e} cert max {float(dc.max()):.2e} frac>1e-3 {frac:.2e}")
-    assert float(dw.max()) < 1e-3 and float(dc.max()) < 1e-3
+    print(f"fp32 e2e 112->168 gp={gp}: warp max {float(dw.max()):.2e} cert max {float(dc.max()):.2e} frac>1e-3 {frac:.2e}")
+    assert float(dw.max()) < 5e-6 and float(dc.max()) < (2e-4 if gp == "fp64" else 1e-3)
 
 
-def test_end_to_end_560_coarse_only_fp32(full_model):
+@pytest.mark.parametrize("gp", GP_MODES)
+def test_end_to_end_560_coarse_only_fp32(full_model, gp):
     g = H.golden("e2e_560")
-    _set_dtype(full_model, torch.float32)
+    _set_dtype(full_model, torch.float32, gp)
     full_model.h_resized = full_model.w_resized = 560
     full_model.upsample_preds = False
     try:
@@ -128,15 +145,16 @@ def test_end_to_end_560_coarse_only_fp32(full_model):
     dw = (warp.cpu()[::8, ::8] - H.T(g["c560_warp_sample"])).abs()
     dc = (cert.cpu()[::8, ::8] - H.T(g["c560_cert_sample"])).abs()
     frac = float((dw > 1e-3).float().mean())
-    print(f"560 coarse fp32: warp max {float(dw.max()):.2e} cert max {float(dc.max()):.2e} frac>1e-3 {frac:.2e}")
-    assert frac < 2e-3 and float(dc.max()) < 2e-3
+    print(f"560 coarse fp32 gp={gp}: warp max {float(dw.max()):.2e} cert max {float(dc.max()):.2e} frac>1e-3 {frac:.2e}")
+    assert float(dw.max()) < E2E_BOUNDS[("c560", gp)][0] and float(dc.max()) < E2E_BOUNDS[("c560", gp)][1]
 
 
-def test_end_to_end_full_560_to_864_fp32(full_model):
+@pytest.mark.parametrize("gp", GP_MODES)
+def test_end_to_end_full_560_to_864_fp32(full_model, gp):
     """BASELINE.json configs[1] on the real pair: full coarse-to-fine 560 -> 864, fp32 mode, against the reference's
-    own output (tests/golden/e2e_864.npz, every 6th pixel + checksums)."""
+    own output (tests/golden/e2e_864.npz, every 6th pixel + checksums).  Bar: 1e-3 max-abs (north_star)."""
     g = H.golden("e2e_864")
-    _set_dtype(full_model, torch.float32)
+    _set_dtype(full_model, torch.float32, gp)
     full_model.h_resized = full_model.w_resized = 560
     full_model.upsample_res = (864, 864)
     try:
@@ -148,11 +166,59 @@ def test_end_to_end_full_560_to_864_fp32(full_model):
     dw = (warp.cpu()[::6, ::6] - H.T(g["warp_sample"])).abs()
     dc = (cert.cpu()[::6, ::6] - H.T(g["cert_sample"])).abs()
     frac_w, frac_c = float((dw > 1e-3).float().mean()), float((dc > 1e-3).float().mean())
-    print(f"560->864 fp32: warp max {float(dw.max()):.2e} frac>1e-3 {frac_w:.2e}; cert max {float(dc.max()):.2e} frac>1e-3 {frac_c:.2e}")
-    # the arg-max over 4096 anchor classes is a hard discontinuity: a flipped coarse pixel moves a whole
-    # neighbourhood, so the full-size check is max-abs where no flip happened plus a bound on the flipped fraction
-    assert frac_w < 2e-3 and frac_c < 2e-2
-    assert float(dw.median()) < 1e-5 and float(dc.median()) < 1e-4
+    print(f"560->864 fp32 gp={gp}: warp max {float(dw.max()):.2e} frac>1e-3 {frac_w:.2e}; cert max {float(dc.max()):.2e} frac>1e-3 {frac_c:.2e}")
+    assert float(dw.max()) < E2E_BOUNDS[("f864", gp)][0] and float(dc.max()) < E2E_BOUNDS[("f864", gp)][1]
+    assert float(dw.median()) < 1e-6 and float(dc.median()) < 1e-4
+
+
+# (warp max-abs, certainty max-abs) bounds; measured values in the comments (MI355X, round 2)
+E2E_BOUNDS = {
+    ("c560", "fp64"): (5e-6, 1e-3),      # measured 2.4e-7 / 5.0e-4
+    ("c560", "fp32"): (1e-3, 3e-3),      # provisional until measured
+    ("f864", "fp64"): (5e-6, 1e-3),      # measured 3.6e-7 / 4.4e-4
+    ("f864", "fp32"): (1e-3, 3e-3),      # provisional until measured
+}
+
+
+def _match_560_864(model, dtype, gp="fp32", record=False):
+    _set_dtype(model, dtype, gp)
+    model.h_resized = model.w_resized = 560
+    model.upsample_res = (864, 864)
+    if record:
+        model.decoder.record = {}
+    try:
+        out = model.match(H.asset("sacre_coeur_A.jpg"), H.asset("sacre_coeur_B.jpg"), device=DEV)
+        rec = model.decoder.record
+    finally:
+        model.h_resized = model.w_resized = 112
+        model.upsample_res = (168, 168)
+        _set_dtype(model, torch.float32)
+    return out, rec
+
+
+def test_fp16_mode_560_to_864_vs_reference_and_argmax_flips(full_model):
+    """The mode bench.py TIMES (fp16 = the reference's GPU autocast semantics) at the headline configuration, against the
+    reference's own (fp32 CPU) output, plus the count of scale-16 arg-max flips against the fp32 mode (the 4096-way arg-max of
+    cls_to_flow_refine, utils.py:316, is the path's one discontinuity; SURVEY §7 measured that rounding the features to fp16
+    moves single pixels by O(1) while p99 stays ~2.6e-4)."""
+    g = H.golden("e2e_864")
+    (w32, c32), r32 = _match_560_864(full_model, torch.float32, record=True)
+    (w16, c16), r16 = _match_560_864(full_model, torch.float16, record=True)
+    assert torch.isfinite(w16).all() and torch.isfinite(c16).all()
+    flips = int((r32["argmax16"] != r16["argmax16"]).sum())
+    dmu = float((r32["mu16"] - r16["mu16"]).abs().max())
+    dw = (w16.cpu()[::6, ::6] - H.T(g["warp_sample"])).abs()
+    dc = (c16.cpu()[::6, ::6] - H.T(g["cert_sample"])).abs()
+    q = lambda t, f: float(t.flatten().kthvalue(max(1, int(t.numel() * f))).values)  # noqa: E731
+    print(f"fp16 560->864 vs reference: warp median {float(dw.median()):.2e} p99 {q(dw, 0.99):.2e} max {float(dw.max()):.2e} "
+          f"frac>1e-3 {float((dw > 1e-3).float().mean()):.2e}; cert median {float(dc.median()):.2e} p99 {q(dc, 0.99):.2e} max {float(dc.max()):.2e}; "
+          f"scale-16 arg-max flips vs fp32 mode {flips}/3200; GP mu max|d| {dmu:.2e}")
+    assert flips <= FP16_BOUNDS["flips"]
+    assert float(dw.median()) < FP16_BOUNDS["warp_median"] and q(dw, 0.99) < FP16_BOUNDS["warp_p99"]
+    assert float(dc.median()) < FP16_BOUNDS["cert_median"] and q(dc, 0.99) < FP16_BOUNDS["cert_p99"]
+
+
+FP16_BOUNDS = {"flips": 400, "warp_median": 2e-3, "warp_p99": 0.5, "cert_median": 2e-3, "cert_p99": 0.2}   # provisional until measured
 
 
 def test_non_square_resolution_vs_oracle(full_model):
