@@ -115,9 +115,11 @@ int roma_kde_density(const float* x, float* density, int N, int down, float std,
  * torch.multinomial(..., replacement=False) draws:  w_i = (thresh >= 0 && p_i > thresh) ? 1 : p_i  (the "threshold" sample
  * mode, matcher.py:474-477);  key_i = w_i / E_i with E_i = -ln(u_i) i.i.d. Exp(1); the k largest keys are a draw of k items
  * without replacement with probabilities proportional to w (what multinomial does internally).  u_i comes from a counter
- * hash of (seed, i) — u = ((fmix32(i * 0x9E3779B1 + seed * 0x85EBCA77 + 0x165667B1) >> 8) + 0.5) / 2^24, fmix32 = the
- * MurmurHash3 finaliser — so a CPU oracle reproduces the draw.  p, keys: (N) fp32; w_i <= 0 (or NaN) gives key 0. */
-int roma_race_keys(const float* p, float* keys, long N, float thresh, unsigned seed, void* stream);
+ * hash of (seed, c_i) — u = ((fmix32(c_i * 0x9E3779B1 + seed * 0x85EBCA77 + 0x165667B1) >> 8) + 0.5) / 2^24, fmix32 = the
+ * MurmurHash3 finaliser — so a CPU oracle reproduces the draw.  c_i = counter[i] (int64, e.g. the item's index in the
+ * population the first draw came from: the second draw then does not depend on the ORDER of the first) or i when counter
+ * is NULL.  p, keys: (N) fp32; w_i <= 0 (or NaN) gives key 0. */
+int roma_race_keys(const float* p, const long* counter, float* keys, long N, float thresh, unsigned seed, void* stream);
 
 /* Pre-processing on the device — utils.py:165-261 (TupleResize = PIL bicubic, ToTensorScaled, TupleNormalize), bit-identical
  * to the host path.  One pass of PIL's 8-bit resampling (Pillow Resample.c): out = clip8((2^21 + sum_k in[lo+k] * coef[k]) >> 22).

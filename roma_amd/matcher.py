@@ -509,7 +509,7 @@ class RegressionMatcher(nn.Module):
         density = ops.kde(good_matches, std=0.1)                                              # fp16, like the reference (:489)
         p = 1 / (density + 1)
         p[density < 10] = 1e-7
-        bal = torch.topk(ops.race_keys(p, -1.0, seed + 1), min(num, len(good_certainty))).indices
+        bal = torch.topk(ops.race_keys(p, -1.0, seed + 1, counter=good), min(num, len(good_certainty))).indices
         return good_matches[bal], good_certainty[bal]
 
     # -- coordinates -----------------------------------------------------------------------------

@@ -414,14 +414,17 @@ def kde(x, std=0.1, half=True, down=None):
     return dens.half() if half else dens
 
 
-def race_keys(p, thresh=-1.0, seed=0):
+def race_keys(p, thresh=-1.0, seed=0, counter=None):
     """Exponential-race keys of sampling without replacement (matcher.py:474-493): key_i = w_i / E_i, w_i = 1 where
-    p_i > thresh >= 0 else p_i, E_i ~ Exp(1) from a counter hash of (seed, i).  topk(keys, k) is a draw of k items without
-    replacement with probabilities proportional to w."""
-    _need_gpu(p)
+    p_i > thresh >= 0 else p_i, E_i ~ Exp(1) from a counter hash of (seed, counter[i] or i).  topk(keys, k) is a draw of k
+    items without replacement with probabilities proportional to w."""
+    _need_gpu(p, counter)
     p = p.reshape(-1).float().contiguous()
+    if counter is not None:
+        counter = counter.reshape(-1).long().contiguous()
+        assert counter.numel() == p.numel()
     keys = torch.empty_like(p)
-    check(_lib.load().roma_race_keys(_p(p), _p(keys), p.numel(), float(thresh), int(seed) & 0xFFFFFFFF, _stream()), "roma_race_keys")
+    check(_lib.load().roma_race_keys(_p(p), _p(counter), _p(keys), p.numel(), float(thresh), int(seed) & 0xFFFFFFFF, _stream()), "roma_race_keys")
     return keys
 
 

@@ -38,7 +38,7 @@ def test_argument_validation_needs_no_gpu():
     assert rc < 0
     rc = lib.roma_add_layernorm(None, 0, 8, None, 0, 8, None, None, None, None, 0, 8, 1, 8, 1e-5, None)
     assert rc == -1 and b"null pointer" in lib.roma_last_error()
-    rc = lib.roma_race_keys(None, None, 4, 0.05, 1, None)
+    rc = lib.roma_race_keys(None, None, None, 4, 0.05, 1, None)
     assert rc == -1
 
 

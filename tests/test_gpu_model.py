@@ -128,7 +128,7 @@ def test_end_to_end_reduced_fp32_vs_reference_golden(full_model, gp):
     dc = (cert.cpu() - H.T(g["r112_cert"])).abs()
     frac = float((dw > 1e-3).float().mean())
     print(f"fp32 e2e 112->168 gp={gp}: warp max {float(dw.max()):.2e} cert max {float(dc.max()):.2e} frac>1e-3 {frac:.2e}")
-    assert float(dw.max()) < 5e-6 and float(dc.max()) < (2e-4 if gp == "fp64" else 1e-3)
+    assert float(dw.max()) < 5e-6 and float(dc.max()) < 2e-4        # measured 3.6e-7 / 4.5e-5 (fp32 GP), 3.9e-5 (fp64 GP)
 
 
 @pytest.mark.parametrize("gp", GP_MODES)
@@ -173,10 +173,10 @@ def test_end_to_end_full_560_to_864_fp32(full_model, gp):
 
 # (warp max-abs, certainty max-abs) bounds; measured values in the comments (MI355X, round 2)
 E2E_BOUNDS = {
-    ("c560", "fp64"): (5e-6, 1e-3),      # measured 2.4e-7 / 5.0e-4
-    ("c560", "fp32"): (1e-3, 3e-3),      # provisional until measured
-    ("f864", "fp64"): (5e-6, 1e-3),      # measured 3.6e-7 / 4.4e-4
-    ("f864", "fp32"): (1e-3, 3e-3),      # provisional until measured
+    ("c560", "fp64"): (5e-6, 1e-3),      # measured 2.4e-7 / 5.2e-4
+    ("c560", "fp32"): (5e-6, 1e-3),      # measured 2.4e-7 / 6.4e-4  (product GP kernels)
+    ("f864", "fp64"): (5e-6, 1e-3),      # measured 3.6e-7 / 4.6e-4
+    ("f864", "fp32"): (5e-6, 1e-3),      # measured 3.6e-7 / 6.2e-4  (product GP kernels): inside the 1e-3 bar of north_star
 }
 
 
@@ -218,7 +218,9 @@ def test_fp16_mode_560_to_864_vs_reference_and_argmax_flips(full_model):
     assert float(dc.median()) < FP16_BOUNDS["cert_median"] and q(dc, 0.99) < FP16_BOUNDS["cert_p99"]
 
 
-FP16_BOUNDS = {"flips": 400, "warp_median": 2e-3, "warp_p99": 0.5, "cert_median": 2e-3, "cert_p99": 0.2}   # provisional until measured
+# measured on MI355X: 17 of 3200 scale-16 arg-max flips vs the fp32 mode; vs the reference's fp32 output: warp median 0, p99 4.3e-2,
+# 2.3 % of entries beyond 1e-3 (the flipped neighbourhoods); certainty median 1.8e-4, p99 2.3e-2.  Bounds = measured x 3.
+FP16_BOUNDS = {"flips": 60, "warp_median": 1e-5, "warp_p99": 0.13, "cert_median": 6e-4, "cert_p99": 7e-2}
 
 
 def test_non_square_resolution_vs_oracle(full_model):
@@ -268,9 +270,11 @@ def test_end_to_end_fp16_mode_bulk_agreement(full_model):
     assert torch.isfinite(warp).all() and torch.isfinite(cert).all()
     dw = (warp.cpu() - H.T(g["r112_warp"])).abs()
     dc = (cert.cpu() - H.T(g["r112_cert"])).abs()
-    print(f"fp16 e2e: warp median {float(dw.median()):.2e} p99 {float(dw.flatten().kthvalue(int(dw.numel()*0.99)).values):.2e} "
-          f"max {float(dw.max()):.2e}; cert max {float(dc.max()):.2e}")
-    assert float(dw.median()) < 5e-3 and float(dc.median()) < 5e-3
+    p99 = float(dw.flatten().kthvalue(int(dw.numel() * 0.99)).values)
+    print(f"fp16 e2e: warp median {float(dw.median()):.2e} p99 {p99:.2e} max {float(dw.max()):.2e}; cert max {float(dc.max()):.2e}")
+    # measured: median 0, p99 8.5e-6, max 1.2e-5, certainty max 5.5e-3 (x3); max-abs is left out because one flipped coarse
+    # arg-max (64 coarse pixels here) would move a neighbourhood
+    assert float(dw.median()) < 1e-5 and p99 < 3e-5 and float(dc.max()) < 2e-2
 
 
 def test_batched_pairs_equal_per_pair_results(full_model):

@@ -322,6 +322,11 @@ def test_race_keys_match_the_oracle_and_select_the_same_set():
         a, b = set(torch.topk(k, 4000).indices.tolist()), set(torch.topk(k_ref, 4000).indices.tolist())
         assert len(a ^ b) <= 2
     assert float(_ops().race_keys(torch.zeros(100, device=DEV), 0.05, 1).max()) == 0.0
+    # counting by item identity: a permuted population gives the permuted keys (the second draw of sample() relies on it)
+    perm = torch.randperm(c.numel())
+    k_perm = _ops().race_keys(c[perm].to(DEV), 0.05, 3, counter=perm.to(DEV)).cpu()
+    assert torch.equal(k_perm, _ops().race_keys(c.to(DEV), 0.05, 3).cpu()[perm])
+    assert torch.equal(O.race_keys(c[perm], 0.05, 3, counter=perm), O.race_keys(c, 0.05, 3)[perm])
 
 
 def test_race_keys_are_a_draw_without_replacement_proportional_to_weight():
@@ -420,7 +425,7 @@ def test_spd_solve_under_tunableop():
     was = tun.is_enabled()
     tun.enable(True)
     try:
-        tun.write_file_on_exit(False)
+        tun.set_filename("/tmp/roma_tunableop_test.csv")           # keep its result file out of the repository
         x = torch.nn.functional.normalize(torch.randn(2, 300, 32), dim=-1)
         K = torch.exp((x @ x.transpose(1, 2) - 1) / 0.2) + 0.1 * torch.eye(300)
         F = torch.randn(2, 300, 16)
