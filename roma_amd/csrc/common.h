@@ -179,6 +179,18 @@ inline int ensure_dyn_smem(const void* fn, int bytes, std::atomic<uint64_t>& mas
   return 0;
 }
 
+// compute units of the current device (cached per device)
+inline int num_cus() {
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  int v = cache[dev & 63].load(std::memory_order_relaxed);
+  if (v > 0) return v;
+  if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+  cache[dev & 63].store(v, std::memory_order_relaxed);
+  return v;
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace roma

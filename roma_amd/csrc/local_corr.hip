@@ -12,7 +12,9 @@
 // (fp16/bf16) or fma (fp32), fp32 accumulation.  D is exchanged through LDS for the 4-tap blend and written out
 // coalesced.  Tiles whose bounding box does not fit in LDS (incoherent flow) read f1 rows straight from L2/HBM.
 #include <type_traits>
+#include <cstdlib>
 #include "common.h"
+#include "local_corr_ring.h"
 
 namespace roma {
 namespace {
@@ -900,6 +902,18 @@ int launch_any(const LCParams& p, hipStream_t s) {
   constexpr int CC = 4 * ElemTraits<T>::kPer16B;                // the fast paths stream whole 64-byte channel chunks
   if (!(p.in_nhwc && p.C % CC == 0)) return launch_lc<T, R>(p, s);
   if constexpr (sizeof(T) == 2) {
+    if constexpr (R <= 3) {
+      // persistent loader / consumer kernel (local_corr_ring.hip), ROMA_LC_RING=1; default: the one-tile-per-workgroup kernel
+      static const bool use_ring = [] { const char* e = getenv("ROMA_LC_RING"); return e && e[0] == '1'; }();   // opt-in until it wins
+      if (use_ring && p.C % 32 == 0 && p.C >= kRingMinC) {
+        LCRingParams q{};
+        q.f0 = p.f0; q.f1 = p.f1; q.flow = p.flow; q.out = p.out;
+        q.B = p.B; q.C = p.C; q.H = p.H; q.W = p.W;
+        q.f0_pitch = p.f0_pitch; q.f1_pitch = p.f1_pitch; q.out_pitch = p.out_pitch;
+        q.out_nhwc = p.out_nhwc; q.f1_shift = p.f1_shift; q.scale = p.scale;
+        return local_corr_ring(q, R, std::is_same<T, half_t>::value ? ROMA_F16 : ROMA_BF16, s);
+      }
+    }
     return launch_lc_mfma<T, R>(p, s);
   } else {
     return launch_lc_nhwc<T, R>(p, s);
