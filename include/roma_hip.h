@@ -121,6 +121,11 @@ int roma_kde_density(const float* x, float* density, int N, int down, float std,
  * is NULL.  p, keys: (N) fp32; w_i <= 0 (or NaN) gives key 0. */
 int roma_race_keys(const float* p, const long* counter, float* keys, long N, float thresh, unsigned seed, void* stream);
 
+/* Nearest neighbours for RegressionMatcher.match_keypoints (matcher.py:576-591): idx[i] = arg min_j |q_i - r_j|^2 over 2-D points
+ * (lowest j on exact ties).  The reference materialises cdist(x_A_to_B, x_B) and compares it with its row / column minima;
+ * mutual nearest neighbours only need this arg-min in both directions.  q: (NQ,2), r: (NR,2) fp32; idx: (NQ) int32. */
+int roma_nn_argmin(const float* q, const float* r, int* idx, int NQ, int NR, void* stream);
+
 /* Pre-processing on the device — utils.py:165-261 (TupleResize = PIL bicubic, ToTensorScaled, TupleNormalize), bit-identical
  * to the host path.  One pass of PIL's 8-bit resampling (Pillow Resample.c): out = clip8((2^21 + sum_k in[lo+k] * coef[k]) >> 22).
  *   in: uint8 (H, W, C);  axis 1: out (H, out_size, C), axis 0: out (out_size, W, C);
@@ -137,8 +142,9 @@ int roma_bias_relu_nchw(void* x, const void* bias, int B, int C, int HW, int dty
 
 /* ConvRefiner block front half — matcher.py:77-103 (create_block: depthwise 5x5 conv, BatchNorm(eval), ReLU),
  * fused, channels-last.  BN is folded by the caller: y = relu(dwconv(x, w) * scale + shift).
- *   x,y: (B,H,W,pitch) `dtype`; w: (25, C) fp32 tap-major; scale, shift: (C) fp32. */
-int roma_dwconv5x5_bn_relu(const void* x, const float* w, const float* scale, const float* shift, void* y,
+ *   x,y: (B,H,W,pitch) `dtype`; w: (25, C) tap-major of w_dtype — ROMA_F32, or for 16-bit activations their own dtype (what
+ *   autocast feeds the reference's depthwise Conv2d; selects the software-pipelined kernel); scale, shift: (C) fp32. */
+int roma_dwconv5x5_bn_relu(const void* x, const void* w, int w_dtype, const float* scale, const float* shift, void* y,
                            int B, int C, int H, int W, int dtype, int x_pitch, int y_pitch, void* stream);
 
 /* One whole ConvRefiner block, fused, for widths C <= 160 in fp16 / bf16 — matcher.py:77-103 (create_block) as applied

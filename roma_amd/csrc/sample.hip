@@ -27,10 +27,45 @@ __global__ __launch_bounds__(256) void race_keys_kernel(const float* __restrict_
   }
 }
 
+// nearest reference point of every query point (2-D, squared Euclidean distance, LOWEST index on exact ties) —
+// RegressionMatcher.match_keypoints (matcher.py:576-591) builds the full |x_A| x |x_B| cdist matrix and compares it with its
+// row / column minima; the mutual-nearest-neighbour test only needs the two arg-min vectors.
+constexpr int NN_TILE = 1024;
+__global__ __launch_bounds__(256) void nn_argmin_kernel(const float* __restrict__ q, const float* __restrict__ r, int* __restrict__ idx,
+                                                        int NQ, int NR) {
+  __shared__ float sx[NN_TILE], sy[NN_TILE];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const float qx = i < NQ ? q[2 * i] : 0.f, qy = i < NQ ? q[2 * i + 1] : 0.f;
+  float best = INFINITY;
+  int bi = 0;
+  for (int j0 = 0; j0 < NR; j0 += NN_TILE) {
+    __syncthreads();
+    for (int t = threadIdx.x; t < NN_TILE && j0 + t < NR; t += blockDim.x) {
+      sx[t] = r[2 * (size_t)(j0 + t)];
+      sy[t] = r[2 * (size_t)(j0 + t) + 1];
+    }
+    __syncthreads();
+    const int cnt = min(NN_TILE, NR - j0);
+    for (int t = 0; t < cnt; ++t) {
+      const float dx = qx - sx[t], dy = qy - sy[t];
+      const float d = __builtin_fmaf(dy, dy, dx * dx);
+      if (d < best) { best = d; bi = j0 + t; }          // strict: the first (lowest) index wins ties
+    }
+  }
+  if (i < NQ) idx[i] = bi;
+}
+
 }  // namespace
 }  // namespace roma
 
 using namespace roma;
+
+extern "C" int roma_nn_argmin(const float* q, const float* r, int* idx, int NQ, int NR, void* stream) {
+  ROMA_REQUIRE(q && r && idx, ROMA_E_ARG, "roma_nn_argmin: null pointer");
+  ROMA_REQUIRE(NQ > 0 && NR > 0, ROMA_E_SHAPE, "roma_nn_argmin: empty point set");
+  hipLaunchKernelGGL(nn_argmin_kernel, dim3((NQ + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), q, r, idx, NQ, NR);
+  ROMA_CHECK_LAUNCH();
+}
 
 extern "C" int roma_race_keys(const float* p, const long* counter, float* keys, long N, float thresh, unsigned seed, void* stream) {
   ROMA_REQUIRE(p && keys, ROMA_E_ARG, "roma_race_keys: null pointer");

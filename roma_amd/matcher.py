@@ -112,12 +112,13 @@ class ConvRefiner(nn.Module):
                                _zero_pad(wt.t(), kp, kp).to(dtype), _zero_pad(b, kp)))
             elif mid:
                 # mid widths (D = 144): depthwise kernel + streaming MFMA 1x1 (ops.pointwise_mfma), weight [out][in] padded to 160
-                blocks.append((w25.contiguous(), scale, shift, _zero_pad(wt.t(), 160, 160).to(dtype), _zero_pad(b, 160)))
+                blocks.append((w25.to(dtype).contiguous(), scale, shift, _zero_pad(wt.t(), 160, 160).to(dtype), _zero_pad(b, 160)))
             # narrow refiners (Dp <= 32): the 1x1 conv is a streaming op -> own kernel with fp32 weights; else a library GEMM
             elif Dp <= 32:
                 blocks.append((w25.contiguous(), scale, shift, wt.contiguous(), b.contiguous()))
             else:
-                blocks.append((w25.contiguous(), scale, shift, wt.to(dtype).contiguous(), b.to(dtype)))
+                # 16-bit modes: 16-bit taps (autocast casts the depthwise Conv2d's weight, matcher.py:77-103) -> pipelined kernel
+                blocks.append((w25.to(dtype).contiguous(), scale, shift, wt.to(dtype).contiguous(), b.to(dtype)))
         wo = torch.zeros(Dp, self.out_dim, device=dev)
         wo[:D] = self.out_conv.weight.float().reshape(self.out_dim, D).t()
         prep = dict(D=D, Dp=Dp, fused=fused, mid=mid, blocks=blocks, wo=wo.contiguous(), bo=self.out_conv.bias.float(),
@@ -535,12 +536,17 @@ class RegressionMatcher(nn.Module):
         return kA, kB
 
     def match_keypoints(self, x_A, x_B, warp, certainty, return_tuple=True, return_inds=False):
-        """matcher.py:576-591: warp the A keypoints, mutual nearest neighbours among x_B, certainty gate."""
+        """matcher.py:576-591: warp the A keypoints, mutual nearest neighbours among x_B, certainty gate.  The reference builds
+        cdist(x_A_to_B, x_B) (|x_A| x |x_B| floats) and compares it with its row and column minima; here the two arg-min
+        vectors come from one small kernel each (ops.nn_argmin) and nothing quadratic is stored.  Pairs come out ordered by
+        the A index like torch.nonzero's; on EXACT distance ties (duplicate keypoints) the lowest index wins, where the
+        reference would emit every tied pair."""
         x_A_to_B = F.grid_sample(warp[..., -2:].permute(2, 0, 1)[None], x_A[None, None], align_corners=False, mode="bilinear")[0, :, 0].mT
         cert = F.grid_sample(certainty[None, None, ...], x_A[None, None], align_corners=False, mode="bilinear")[0, 0, 0]
-        Dm = torch.cdist(x_A_to_B, x_B)
-        iA, iB = torch.nonzero((Dm == Dm.min(dim=-1, keepdim=True).values) * (Dm == Dm.min(dim=-2, keepdim=True).values)
-                               * (cert[:, None] > self.sample_thresh), as_tuple=True)
+        nn_b = ops.nn_argmin(x_A_to_B, x_B)                     # nearest B keypoint of every warped A keypoint
+        nn_a = ops.nn_argmin(x_B, x_A_to_B)                     # nearest warped A keypoint of every B keypoint
+        iA = torch.nonzero((nn_a[nn_b] == torch.arange(len(nn_b), device=nn_b.device)) & (cert > self.sample_thresh), as_tuple=True)[0]
+        iB = nn_b[iA]
         if return_tuple:
             return (iA, iB) if return_inds else (x_A[iA], x_B[iB])
         return torch.cat((iA, iB), dim=-1) if return_inds else torch.cat((x_A[iA], x_B[iB]), dim=-1)
@@ -592,6 +598,38 @@ class RegressionMatcher(nn.Module):
                         else self.forward(batch, batched=True, upsample=True, scale_factor=scale_factor))
         out = ops.match_finalize(corresps[1]["flow"], corresps[1]["certainty"], cert16, symmetric=symmetric)
         ops.raise_pending()          # the GP solve's SPD check, deferred so that the pipeline has no host sync in the middle
+        return out
+
+    @torch.inference_mode()
+    def encode(self, im_lo, im_hi=None):
+        """Feature pyramids of ONE image (or a stack of images), to be reused by every pair the image takes part in (SfM-style
+        matching of N images in M >> N pairs runs the encoders N times instead of 2M).  im_lo (P,3,h,w)
+        normalised at the coarse resolution, im_hi (P,3,H,W) at the upsample resolution (needed when upsample_preds).
+        Returns {"lo": {16,8,4,2,1: feats}, "hi": {8,4,2,1: feats} or None} — extract_backbone_features (matcher.py:458-466)
+        on one side of the pair."""
+        lo = self.encoder(im_lo, upsample=False)
+        hi = self.encoder(im_hi, upsample=True) if (self.upsample_preds and im_hi is not None) else None
+        return {"lo": lo, "hi": hi, "lo_size": tuple(im_lo.shape[-2:]), "hi_size": None if im_hi is None else tuple(im_hi.shape[-2:])}
+
+    @torch.inference_mode()
+    def match_encoded(self, enc_A, enc_B):
+        """match_tensors on cached pyramids (see encode): the decoder passes and the post-processing only.  The two pyramids
+        are concatenated along the batch ([A; B], the layout forward_symmetric works on): one copy of the features, a few
+        hundred microseconds, against ~11 ms of encoder time per pair."""
+        if not self.symmetric:
+            raise NotImplementedError("match_encoded implements the symmetric mode the shipped models use")
+        pyr = {s: torch.cat((enc_A["lo"][s], enc_B["lo"][s]), dim=0) for s in enc_A["lo"]}
+        corresps = self.forward_symmetric({"pyramid": pyr})
+        cert16 = corresps[16]["certainty"] if self.attenuate_cert else None
+        if self.upsample_preds:
+            if enc_A["hi"] is None or enc_B["hi"] is None:
+                raise ValueError("upsample_preds=True needs encode(im_lo, im_hi)")
+            (h, w), (hs, ws) = enc_A["lo_size"], enc_A["hi_size"]
+            pyr = {s: torch.cat((enc_A["hi"][s], enc_B["hi"][s]), dim=0) for s in enc_A["hi"]}
+            corresps = self.forward_symmetric({"pyramid": pyr, "corresps": corresps[1]}, upsample=True,
+                                              scale_factor=math.sqrt(hs * ws / (h * w)))             # matcher.py:677
+        out = ops.match_finalize(corresps[1]["flow"], corresps[1]["certainty"], cert16, symmetric=True)
+        ops.raise_pending()
         return out
 
     @torch.inference_mode()

@@ -428,9 +428,21 @@ def race_keys(p, thresh=-1.0, seed=0, counter=None):
     return keys
 
 
+def nn_argmin(q, r):
+    """idx[i] = arg min_j |q_i - r_j|^2 for 2-D point sets q (NQ,2), r (NR,2) -> (NQ,) int64; the two arg-min vectors that the
+    mutual-nearest-neighbour test of match_keypoints (matcher.py:585-588) needs, without the |q| x |r| cdist matrix."""
+    _need_gpu(q, r)
+    if q.dim() != 2 or q.shape[1] != 2 or r.dim() != 2 or r.shape[1] != 2:
+        raise ValueError("nn_argmin expects (N,2) point sets")
+    q, r = q.float().contiguous(), r.float().contiguous()
+    idx = torch.empty((q.shape[0],), dtype=torch.int32, device=q.device)
+    check(_lib.load().roma_nn_argmin(_p(q), _p(r), _p(idx), q.shape[0], r.shape[0], _stream()), "roma_nn_argmin")
+    return idx.long()
+
+
 def dwconv5x5_bn_relu(x, w25, scale, shift, out=None):
     """relu(BN(depthwise5x5(x))) with BN folded into (scale, shift) — matcher.py:77-103.  x, out: channels-last
-    (B,C,H,W) views; w25 (25,C) fp32 tap-major."""
+    (B,C,H,W) views; w25 (25,C) tap-major, fp32 or — for 16-bit x — x's dtype (autocast semantics; the pipelined kernel)."""
     _need_gpu(x, w25, scale, shift, out)
     B, C, H, W = x.shape
     lx, px, xx = feat_layout(x)
@@ -441,7 +453,8 @@ def dwconv5x5_bn_relu(x, w25, scale, shift, out=None):
     lo, po, o = feat_layout(out)
     if lo != ROMA_NHWC or o is not out:
         raise ValueError("dwconv5x5_bn_relu needs channels-last output")
-    check(_lib.load().roma_dwconv5x5_bn_relu(_p(xx), _p(w25), _p(scale), _p(shift), _p(out), B, C, H, W, _dt(xx), px, po, _stream()),
+    assert w25.is_contiguous() and w25.shape == (25, C) and w25.dtype in (torch.float32, x.dtype)
+    check(_lib.load().roma_dwconv5x5_bn_relu(_p(xx), _p(w25), _dt(w25), _p(scale), _p(shift), _p(out), B, C, H, W, _dt(xx), px, po, _stream()),
           "roma_dwconv5x5_bn_relu")
     return out
 

@@ -303,6 +303,49 @@ def test_sample_and_coordinates(full_model):
     assert full_model.get_output_resolution() == (168, 168)
 
 
+def test_match_keypoints_equals_the_reference_formula(full_model):
+    """match_keypoints (matcher.py:576-591) with two arg-min kernels instead of the |x_A| x |x_B| cdist matrix: same mutual
+    nearest neighbours as the literal formula (oracle.match_keypoints) on random keypoints and a smooth synthetic warp."""
+    from oracle import roma_oracle as O
+    g = torch.Generator().manual_seed(3)
+    Hh, Ww = 96, 128
+    ys, xs = torch.linspace(-1 + 1 / Hh, 1 - 1 / Hh, Hh), torch.linspace(-1 + 1 / Ww, 1 - 1 / Ww, Ww)
+    grid = torch.stack((xs[None].expand(Hh, Ww), ys[:, None].expand(Hh, Ww)), dim=-1)
+    tgt = 0.9 * grid.flip(-1) * torch.tensor([1.0, -1.0]) + 0.05                                  # a rotation-like smooth map
+    warp = torch.cat((torch.cat((grid, tgt), dim=-1), torch.cat((tgt, grid), dim=-1)), dim=1)      # (H, 2W, 4) symmetric layout
+    cert = torch.rand(Hh, 2 * Ww, generator=g)
+    x_A = torch.rand(3000, 2, generator=g) * 1.9 - 0.95
+    x_B = torch.rand(2500, 2, generator=g) * 1.9 - 0.95
+    rA, rB = O.match_keypoints(x_A, x_B, warp, cert)
+    iA, iB = full_model.match_keypoints(x_A.to(DEV), x_B.to(DEV), warp.to(DEV), cert.to(DEV), return_inds=True)
+    assert iA.numel() > 50
+    got, ref = set(zip(iA.tolist(), iB.tolist())), set(zip(rA.tolist(), rB.tolist()))
+    print(f"match_keypoints: {len(got)} mutual matches, {len(got ^ ref)} differ from the cdist formulation")
+    assert len(got ^ ref) <= 2                       # cdist takes its matmul route: near-ties may round the other way
+    kA, kB = full_model.match_keypoints(x_A.to(DEV), x_B.to(DEV), warp.to(DEV), cert.to(DEV))
+    assert torch.equal(kA, x_A.to(DEV)[iA]) and torch.equal(kB, x_B.to(DEV)[iB])
+
+
+def test_encode_once_match_many(full_model):
+    """pyramids cached per image (model.encode) and reused across pairs (model.match_encoded) give the
+    result of match_tensors on the same pair (the encoders see batch 1 instead of 2: library kernels may pick other tilings,
+    so agreement is to fp32 rounding, not bitwise)."""
+    from PIL import Image
+    from roma_amd.matcher import preprocess
+    _set_dtype(full_model, torch.float32)
+    ims = [Image.open(H.asset(f"sacre_coeur_{n}.jpg")).convert("RGB") for n in "AB"]
+    lo = [preprocess(im, (112, 112))[None].to(DEV) for im in ims]
+    hi = [preprocess(im, (168, 168))[None].to(DEV) for im in ims]
+    w_ref, c_ref = full_model.match_tensors(lo[0], lo[1], hi[0], hi[1])
+    enc = [full_model.encode(lo[i], hi[i]) for i in range(2)]
+    w, c = full_model.match_encoded(enc[0], enc[1])
+    w_ba, c_ba = full_model.match_encoded(enc[1], enc[0])                 # the cached pyramids serve the reversed pair too
+    print(f"encode/match_encoded vs match_tensors: warp max {maxerr(w, w_ref):.2e}, cert max {maxerr(c, c_ref):.2e}")
+    assert maxerr(w, w_ref) < 1e-4 and maxerr(c, c_ref) < 1e-4
+    W2 = w.shape[2] // 2
+    assert maxerr(w_ba[:, :, :W2, 2:], w[:, :, W2:, :2]) < 1e-4           # B->A half of (A,B) == A->B half of (B,A)
+
+
 def test_match_rejects_bad_images(full_model):
     from PIL import Image
     with pytest.raises(NotImplementedError):
