@@ -60,6 +60,8 @@ def main():
     for D, h in [(1384, 40), (1144, 70), (576, 140), (144, 280), (24, 560), (1144, 108), (576, 216), (144, 432), (24, 864)]:
         x = torch.randn(B, D, h, h, device="cuda").to(dt).contiguous(memory_format=torch.channels_last)
         w = torch.randn(25, D, device="cuda")
+        if dt != torch.float32 and os.environ.get("ROMA_DW_TAPS", "16") == "16":
+            w = w.to(dt)                     # autocast semantics: 16-bit taps (the kernel the 16-bit pipeline runs)
         sc, sh = torch.rand(D, device="cuda") + 0.5, torch.randn(D, device="cuda")
         y = torch.empty_like(x)
         t = timeit(lambda: ops.dwconv5x5_bn_relu(x, w, sc, sh, out=y), iters=20)
@@ -71,14 +73,28 @@ def main():
     y = torch.randn(B, 1600, 512, device="cuda")
     t = timeit(lambda: ops.cos_kernel(x, y), iters=20)
     print(f"cos_kernel B={B} 1600x1600x512 fp32-MFMA: {t*1e6:.1f} us  {2*B*1600*1600*512/t/1e12:.1f} TFLOP/s")
+    xn = torch.nn.functional.normalize(torch.randn(2, 1600, 64, device="cuda"), dim=-1)
+    K = torch.exp((xn @ xn.transpose(1, 2) - 1) / 0.2) + 0.1 * torch.eye(1600, device="cuda")
+    F = torch.randn(1, 1600, 512, device="cuda")
+    t = timeit(lambda: ops.spd_solve(K, F, check=None), 10, 2)
+    print(f"spd_solve B=2 n=1600 m=512 (25 diagonal blocks + 100 GEMMs): {t*1e3:.3f} ms", flush=True)
+    A = K[:, :64, :64].contiguous()
+    Wb = torch.empty(2, 64, 64, device="cuda")
+    info = torch.zeros(2, dtype=torch.int32, device="cuda")
+    from roma_amd import _lib
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    t = timeit(lambda: lib.roma_chol_diag_block(A.data_ptr(), 64, 64 * 64, Wb.data_ptr(), 64, 64 * 64, 64, 2, info.data_ptr(), 0, st), 50)
+    print(f"chol_diag_block 64x64 B=2: {t*1e6:.1f} us per launch (back to back: A is re-factored, timing only)", flush=True)
     rows = torch.randn(B, 1600, 4097, device="cuda").to(dt)
     t = timeit(lambda: ops.cls_rows_to_flow(rows, B, 40, 40), iters=20)
     print(f"cls_rows_to_flow: {t*1e6:.1f} us  {rows.numel()*es/t/1e9:.1f} GB/s")
     # warp (grid_sample) at the refiner shapes, finalize, narrow pointwise, fused head, tiny corr+soft-argmax
-    for C, h in [(512, 40), (512, 70), (256, 140), (64, 280), (512, 108), (256, 216), (64, 432)]:
-        y = torch.randn(B, C, h, h, device="cuda").to(dt).contiguous(memory_format=torch.channels_last)
+    for C, h in [(512, 40), (512, 70), (256, 140), (64, 280), (9, 560), (512, 108), (256, 216), (64, 432), (9, 864)]:
+        pitch = 24 if C == 9 else C          # the scale-1 refiner warps 9 channels inside its 24-channel pixel
+        y = torch.randn(B, h, h, pitch, device="cuda").to(dt)[..., :C].permute(0, 3, 1, 2)
         flow = torch.from_numpy(R.coherent_flow("bench", B, h, h)).cuda()
-        o = ops.nhwc_empty(B, C, h, h, dt, "cuda")
+        o = ops.nhwc_empty(B, C, h, h, dt, "cuda", pitch=pitch)
         t = timeit(lambda: ops.warp_bilinear(y, flow, out=o), iters=20)
         nb = 2 * B * C * h * h * es + B * 2 * h * h * 4
         print(f"warp_bilinear C={C} h={h}: {t*1e6:8.1f} us {nb/1e6:8.2f} MB {nb/t/1e9:8.1f} GB/s", flush=True)
