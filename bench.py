@@ -49,6 +49,7 @@ def parse_args(argv=None):
     ap.add_argument("--workload", default="outdoor", choices=["outdoor", "indoor_sample", "tiny"])
     ap.add_argument("--pairs", type=int, default=0, help="image pairs per GPU per step (weak scaling); 0 = the workload's default (1 / 8 / 256)")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16", "fp32"])
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / parity legs")
     ap.add_argument("--no-microbench", action="store_true", help="skip the standalone local_corr launches (for --pmc passes over the pipeline only)")
     return ap.parse_args(argv)
@@ -253,9 +254,21 @@ def make_workload(args, device, dtype, rank, P):
         pairs = [synthetic_pair(first + i) for i in range(P)]
         A_lo, B_lo, A_hi, B_hi = (torch.cat([p[j] for p in pairs]).to(device) for j in range(4))
         if args.workload == "outdoor":
+            graphed = None
+            if not args.no_graph:
+                try:                                              # one hipGraph per step: ~900 launches replayed by one host call
+                    graphed = model.make_graphed(A_lo, B_lo, A_hi, B_hi)
+                except Exception as e:                            # noqa: BLE001 — capture is an optimisation, the eager path is the same kernels
+                    log(f"[bench] hipGraph capture failed ({e!r}); running eagerly")
+                    torch.cuda.synchronize()
+
             def step():
+                if graphed is not None:
+                    return graphed(A_lo, B_lo, A_hi, B_hi)
                 return model.match_tensors(A_lo, B_lo, A_hi, B_hi)
-            cfg = {"workload": "roma_outdoor 560->864 full coarse-to-fine symmetric match (BASELINE configs[1]; configs[2] = --pairs 8 --gpus 8)"}
+            step.eager = lambda: model.match_tensors(A_lo, B_lo, A_hi, B_hi)
+            cfg = {"workload": "roma_outdoor 560->864 full coarse-to-fine symmetric match (BASELINE configs[1]; configs[2] = --pairs 8 --gpus 8)",
+                   "launch": "one captured hipGraph per step (both HIP streams of the step inside it)" if graphed is not None else "eager launches"}
         else:
             it = [rank]
 
@@ -414,6 +427,19 @@ def main():
     else:
         n_distinct = 1
 
+    eager = getattr(run, "eager", None)
+    if rank == 0 and eager is not None and "hipGraph" in cfg.get("launch", ""):
+        # A graph replay offers no per-kernel events: the local_corr launches are timed with HIP events over an EAGER run of the
+        # same steps (same kernels, same inputs, same streams) right after the timed region.
+        n_ev = max(3, min(args.steps, 10))
+        eager()
+        torch.cuda.synchronize()
+        ops.TIMER.start()
+        for _ in range(n_ev):
+            eager()
+        torch.cuda.synchronize()
+        ops.TIMER.stop()
+        cfg["roofline_events"] = f"HIP events on the launch stream over {n_ev} eager steps run right after the timed graph replays"
     if rank == 0:
         summ = ops.TIMER.summary()
         roof = None

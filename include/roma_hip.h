@@ -142,9 +142,8 @@ int roma_bias_relu_nchw(void* x, const void* bias, int B, int C, int HW, int dty
 
 /* ConvRefiner block front half — matcher.py:77-103 (create_block: depthwise 5x5 conv, BatchNorm(eval), ReLU),
  * fused, channels-last.  BN is folded by the caller: y = relu(dwconv(x, w) * scale + shift).
- *   x,y: (B,H,W,pitch) `dtype`; w: (25, C) tap-major of w_dtype — ROMA_F32, or for 16-bit activations their own dtype (what
- *   autocast feeds the reference's depthwise Conv2d; selects the software-pipelined kernel); scale, shift: (C) fp32. */
-int roma_dwconv5x5_bn_relu(const void* x, const void* w, int w_dtype, const float* scale, const float* shift, void* y,
+ *   x,y: (B,H,W,pitch) `dtype`; w: (25, C) fp32 tap-major; scale, shift: (C) fp32. */
+int roma_dwconv5x5_bn_relu(const void* x, const float* w, const float* scale, const float* shift, void* y,
                            int B, int C, int H, int W, int dtype, int x_pitch, int y_pitch, void* stream);
 
 /* One whole ConvRefiner block, fused, for widths C <= 160 in fp16 / bf16 — matcher.py:77-103 (create_block) as applied

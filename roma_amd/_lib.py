@@ -33,7 +33,7 @@ SIGNATURES = {
     "roma_kde_density": [c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p],
     "roma_nn_argmin": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "roma_race_keys": [c_void_p, c_void_p, c_void_p, c_long, c_float, ctypes.c_uint, c_void_p],
-    "roma_dwconv5x5_bn_relu": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "roma_dwconv5x5_bn_relu": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "roma_resample_u8": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p],
     "roma_normalize_u8": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "roma_bias_relu_nchw": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],

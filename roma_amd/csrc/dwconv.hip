@@ -7,7 +7,6 @@
 // reuses every loaded packet for up to 5 taps x XS outputs; fp32 accumulation.  Lanes run along the channel
 // packets, so a wavefront's loads are 1 KiB contiguous for C >= 512 (fp16).
 #include <cstdlib>
-#include <type_traits>
 #include "common.h"
 
 namespace roma {
@@ -109,104 +108,6 @@ __global__ __launch_bounds__(256, MINW) void dwconv5x5_kernel(const T* __restric
   }
 }
 
-// 16-bit activations with 16-bit taps (what autocast gives the reference's depthwise Conv2d, matcher.py:77-103).  Same register
-// tile as the kernel above (one 16-byte channel packet x XS output pixels, one input row in registers at a time, rolled row
-// loop), but the five tap packets of a row are 16-bit (5 loads per row instead of 10 float4, 20 registers instead of 40) and
-// both factors of every product stay packed in their registers (one v_fma_mix_f32 per product for fp16).
-// (An unrolled, explicitly double-buffered version was tried: hipcc floats all five rows' loads to the top whatever barriers are
-// placed — 256 VGPRs and scratch spills.)
-template <typename T, int XS, int MINW>
-__global__ __launch_bounds__(256, MINW) void dwconv5x5_pipe_kernel(const T* __restrict__ x, const T* __restrict__ w,
-                                                             const float* __restrict__ scale, const float* __restrict__ shift,
-                                                             T* __restrict__ y, int B, int C, int H, int W, int x_pitch, int y_pitch) {
-  constexpr int E = 8, NC = XS + 4;
-  const int PK = C / E;
-  const int WS = (W + XS - 1) / XS;
-  const size_t total = (size_t)B * H * WS * PK;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int k = (int)(i % PK);
-    size_t r = i / PK;
-    const int xs = (int)(r % WS) * XS; r /= WS;
-    const int yo = (int)(r % H);
-    const int b = (int)(r / H);
-    const int c0 = k * E;
-    const T* xb = x + (size_t)b * H * W * x_pitch + c0;
-    const T* wb = w + c0;
-    const bool interior = yo >= 2 && yo + 3 <= H && xs >= 2 && xs + XS + 2 <= W;
-    float acc[XS][E];
-#pragma unroll
-    for (int o = 0; o < XS; ++o)
-#pragma unroll
-      for (int e = 0; e < E; ++e) acc[o][e] = 0.f;
-#pragma unroll 1
-    for (int iy = 0; iy < 5; ++iy) {                              // rolled: one input row in registers at a time
-      const int yi = yo + iy - 2;
-      const T* row = xb + (size_t)min(max(yi, 0), H - 1) * W * x_pitch;
-      u32x4 raw[NC], wc[5];
-      if (interior) {
-#pragma unroll
-        for (int cx = 0; cx < NC; ++cx) raw[cx] = *reinterpret_cast<const u32x4*>(row + (size_t)(xs - 2 + cx) * x_pitch);
-      } else {
-        const bool rowok = yi >= 0 && yi < H;
-#pragma unroll
-        for (int cx = 0; cx < NC; ++cx) {
-          const int xi = xs - 2 + cx;
-          const u32x4 v = *reinterpret_cast<const u32x4*>(row + (size_t)min(max(xi, 0), W - 1) * x_pitch);
-          raw[cx] = (rowok && xi >= 0 && xi < W) ? v : u32x4{0, 0, 0, 0};
-        }
-      }
-#pragma unroll
-      for (int dx = 0; dx < 5; ++dx) wc[dx] = *reinterpret_cast<const u32x4*>(wb + (size_t)(iy * 5 + dx) * C);
-#pragma unroll
-      for (int cx = 0; cx < NC; ++cx) {
-#pragma unroll
-        for (int dx = 0; dx < 5; ++dx) {
-          const int o = cx - dx;
-          if (o >= 0 && o < XS) {
-#pragma unroll
-            for (int e2 = 0; e2 < 4; ++e2) {
-              const uint32_t ux = raw[cx][e2], uw = wc[dx][e2];
-              if constexpr (std::is_same<T, half_t>::value) {
-                const half2_t hx = __builtin_bit_cast(half2_t, ux), hw = __builtin_bit_cast(half2_t, uw);
-                acc[o][2 * e2] = __builtin_fmaf((float)hx[0], (float)hw[0], acc[o][2 * e2]);
-                acc[o][2 * e2 + 1] = __builtin_fmaf((float)hx[1], (float)hw[1], acc[o][2 * e2 + 1]);
-              } else {
-                acc[o][2 * e2] = __builtin_fmaf(__uint_as_float(ux << 16), __uint_as_float(uw << 16), acc[o][2 * e2]);
-                acc[o][2 * e2 + 1] = __builtin_fmaf(__uint_as_float(ux & 0xffff0000u), __uint_as_float(uw & 0xffff0000u), acc[o][2 * e2 + 1]);
-              }
-            }
-          }
-        }
-      }
-    }
-    float sc[E], sh[E];
-#pragma unroll
-    for (int e = 0; e < E; e += 4) {
-      *reinterpret_cast<float4_t*>(&sc[e]) = *reinterpret_cast<const float4_t*>(scale + c0 + e);
-      *reinterpret_cast<float4_t*>(&sh[e]) = *reinterpret_cast<const float4_t*>(shift + c0 + e);
-    }
-    T* yrow = y + (((size_t)b * H + yo) * W) * y_pitch + c0;
-#pragma unroll
-    for (int o = 0; o < XS; ++o) {
-      if (xs + o >= W) break;
-      float v[E];
-#pragma unroll
-      for (int e = 0; e < E; ++e) v[e] = fmaxf(__builtin_fmaf(acc[o][e], sc[e], sh[e]), 0.f);
-      *reinterpret_cast<u32x4*>(yrow + (size_t)(xs + o) * y_pitch) = pack16<T>(v);
-    }
-  }
-}
-
-template <typename T, int XS, int MINW>
-void launch_dw_pipe(const void* x, const void* w, const float* scale, const float* shift, void* y, int B, int C, int H, int W,
-                    int x_pitch, int y_pitch, hipStream_t s) {
-  const size_t total = (size_t)B * H * ((W + XS - 1) / XS) * (C / 8);
-  size_t g = (total + 255) / 256;
-  if (g > 32768) g = 32768;
-  hipLaunchKernelGGL((dwconv5x5_pipe_kernel<T, XS, MINW>), dim3((int)g), dim3(256), 0, s, (const T*)x, (const T*)w, scale, shift, (T*)y, B, C, H, W,
-                     x_pitch, y_pitch);
-}
-
 template <typename T, int XS, int YS, int MINW = 1>
 void launch_dw(const void* x, const float* w, const float* scale, const float* shift, void* y, int B, int C, int H, int W,
                int x_pitch, int y_pitch, hipStream_t s) {
@@ -222,8 +123,8 @@ void launch_dw(const void* x, const float* w, const float* scale, const float* s
 
 using namespace roma;
 
-extern "C" int roma_dwconv5x5_bn_relu(const void* x, const void* w, int w_dtype, const float* scale, const float* shift, void* y, int B,
-                                      int C, int H, int W, int dtype, int x_pitch, int y_pitch, void* stream) {
+extern "C" int roma_dwconv5x5_bn_relu(const void* x, const float* w, const float* scale, const float* shift, void* y, int B, int C,
+                                      int H, int W, int dtype, int x_pitch, int y_pitch, void* stream) {
   ROMA_REQUIRE(x && w && scale && shift && y, ROMA_E_ARG, "roma_dwconv5x5_bn_relu: null pointer");
   ROMA_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && x_pitch >= C && y_pitch >= C, ROMA_E_SHAPE, "roma_dwconv5x5_bn_relu: bad shape");
   ROMA_REQUIRE(dtype >= ROMA_F32 && dtype <= ROMA_BF16, ROMA_E_DTYPE, "roma_dwconv5x5_bn_relu: unknown dtype %d", dtype);
@@ -231,26 +132,7 @@ extern "C" int roma_dwconv5x5_bn_relu(const void* x, const void* w, int w_dtype,
   ROMA_REQUIRE(C % e == 0 && x_pitch % e == 0 && y_pitch % e == 0 && aligned16(x) && aligned16(y) && aligned16(w) &&
                    aligned16(scale) && aligned16(shift),
                ROMA_E_ALIGN, "roma_dwconv5x5_bn_relu: C and pitches must be multiples of %d, all bases 16-byte aligned", e);
-  ROMA_REQUIRE(w_dtype == ROMA_F32 || (w_dtype == dtype && dtype != ROMA_F32), ROMA_E_DTYPE,
-               "roma_dwconv5x5_bn_relu: taps must be fp32, or the activations' 16-bit dtype");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (w_dtype != ROMA_F32) {
-    // variant = XS * 10 + minimum waves per SIMD (register cap); ROMA_DW_PIPE overrides (tuning aid)
-    static int variant = -1;
-    if (variant < 0) { const char* ev = getenv("ROMA_DW_PIPE"); variant = ev ? atoi(ev) : 43; }
-#define ROMA_DWP(T)                                                                                          \
-    switch (variant) {                                                                                       \
-      case 82: launch_dw_pipe<T, 8, 2>(x, w, scale, shift, y, B, C, H, W, x_pitch, y_pitch, s); break;       \
-      case 83: launch_dw_pipe<T, 8, 3>(x, w, scale, shift, y, B, C, H, W, x_pitch, y_pitch, s); break;       \
-      case 42: launch_dw_pipe<T, 4, 2>(x, w, scale, shift, y, B, C, H, W, x_pitch, y_pitch, s); break;       \
-      case 44: launch_dw_pipe<T, 4, 4>(x, w, scale, shift, y, B, C, H, W, x_pitch, y_pitch, s); break;       \
-      default: launch_dw_pipe<T, 4, 3>(x, w, scale, shift, y, B, C, H, W, x_pitch, y_pitch, s); break;       \
-    }
-    if (dtype == ROMA_F16) { ROMA_DWP(half_t) } else { ROMA_DWP(bf16_t) }
-#undef ROMA_DWP
-    ROMA_CHECK_LAUNCH();
-  }
-  const float* wf32 = static_cast<const float*>(w);
   // tile shape: ROMA_DW_TILE=XSxYS overrides (tuning aid); default 8x1
   static int tile = -1;
   if (tile < 0) {
@@ -259,11 +141,11 @@ extern "C" int roma_dwconv5x5_bn_relu(const void* x, const void* w, int w_dtype,
   }
 #define ROMA_DW(T)                                                                                                    \
   switch (tile) {                                                                                                     \
-    case 41: launch_dw<T, 4, 1>(x, wf32, scale, shift, y, B, C, H, W, x_pitch, y_pitch, s); break;                       \
-    case 42: launch_dw<T, 4, 2>(x, wf32, scale, shift, y, B, C, H, W, x_pitch, y_pitch, s); break;                       \
-    case 82: launch_dw<T, 8, 2>(x, wf32, scale, shift, y, B, C, H, W, x_pitch, y_pitch, s); break;                       \
-    case 44: launch_dw<T, 4, 4>(x, wf32, scale, shift, y, B, C, H, W, x_pitch, y_pitch, s); break;                       \
-    default: launch_dw<T, 8, 1>(x, wf32, scale, shift, y, B, C, H, W, x_pitch, y_pitch, s); break;                       \
+    case 41: launch_dw<T, 4, 1>(x, w, scale, shift, y, B, C, H, W, x_pitch, y_pitch, s); break;                       \
+    case 42: launch_dw<T, 4, 2>(x, w, scale, shift, y, B, C, H, W, x_pitch, y_pitch, s); break;                       \
+    case 82: launch_dw<T, 8, 2>(x, w, scale, shift, y, B, C, H, W, x_pitch, y_pitch, s); break;                       \
+    case 44: launch_dw<T, 4, 4>(x, w, scale, shift, y, B, C, H, W, x_pitch, y_pitch, s); break;                       \
+    default: launch_dw<T, 8, 1>(x, w, scale, shift, y, B, C, H, W, x_pitch, y_pitch, s); break;                       \
   }
   if (dtype == ROMA_F32) { ROMA_DW(float) } else if (dtype == ROMA_F16) { ROMA_DW(half_t) } else { ROMA_DW(bf16_t) }
 #undef ROMA_DW

@@ -112,13 +112,12 @@ class ConvRefiner(nn.Module):
                                _zero_pad(wt.t(), kp, kp).to(dtype), _zero_pad(b, kp)))
             elif mid:
                 # mid widths (D = 144): depthwise kernel + streaming MFMA 1x1 (ops.pointwise_mfma), weight [out][in] padded to 160
-                blocks.append((w25.to(dtype).contiguous(), scale, shift, _zero_pad(wt.t(), 160, 160).to(dtype), _zero_pad(b, 160)))
+                blocks.append((w25.contiguous(), scale, shift, _zero_pad(wt.t(), 160, 160).to(dtype), _zero_pad(b, 160)))
             # narrow refiners (Dp <= 32): the 1x1 conv is a streaming op -> own kernel with fp32 weights; else a library GEMM
             elif Dp <= 32:
                 blocks.append((w25.contiguous(), scale, shift, wt.contiguous(), b.contiguous()))
             else:
-                # 16-bit modes: 16-bit taps (autocast casts the depthwise Conv2d's weight, matcher.py:77-103) -> pipelined kernel
-                blocks.append((w25.to(dtype).contiguous(), scale, shift, wt.to(dtype).contiguous(), b.to(dtype)))
+                blocks.append((w25.contiguous(), scale, shift, wt.to(dtype).contiguous(), b.to(dtype)))
         wo = torch.zeros(Dp, self.out_dim, device=dev)
         wo[:D] = self.out_conv.weight.float().reshape(self.out_dim, D).t()
         prep = dict(D=D, Dp=Dp, fused=fused, mid=mid, blocks=blocks, wo=wo.contiguous(), bo=self.out_conv.bias.float(),
@@ -405,8 +404,9 @@ class Decoder(nn.Module):
                 if npad > n:
                     tokens[:, n:].zero_()
                 tokens[:, :n, gp.dim:].copy_(xs)
+                capturing = torch.cuda.is_current_stream_capturing()
                 gp.posterior_rows(xs, ys, hs, ws, fp64=(self.gp_precision == "fp64"), batch_shift=shift,
-                                  out=tokens[:, :n, :gp.dim], check="defer")                   # :377
+                                  out=tokens[:, :n, :gp.dim], check=None if capturing else "defer")   # :377
                 # The reference runs this transformer under autocast (transformer/__init__.py:31-32): fp32 token / residual
                 # stream and LayerNorm, amp-dtype GEMMs / attention / logits.  Autocast re-casts every weight on every call
                 # (0.26 ms of copy kernels per pair), so the 16-bit modes run a cached copy of the module whose Linear weights
@@ -599,6 +599,33 @@ class RegressionMatcher(nn.Module):
         out = ops.match_finalize(corresps[1]["flow"], corresps[1]["certainty"], cert16, symmetric=symmetric)
         ops.raise_pending()          # the GP solve's SPD check, deferred so that the pipeline has no host sync in the middle
         return out
+
+    def make_graphed(self, A_lo, B_lo, A_hi=None, B_hi=None, warmup=2):
+        """match_tensors for ONE fixed batch shape as a captured hipGraph (torch.cuda.CUDAGraph is hipGraph on ROCm): the
+        ~900 launches of a step — both streams of the plan in match_tensors, every library GEMM / convolution and every
+        kernel of libroma_hip.so — are recorded once and replayed with one host call, which removes the host launch gaps
+        between the small dependent kernels (GP chain, decoder transformer, narrow levels).  Returns run(A_lo, B_lo, A_hi,
+        B_hi) -> (warp, certainty): inputs are copied into the graph's static buffers (same shapes as here), outputs are the
+        graph's static tensors (clone them if they must survive the next call).  The SPD check of the GP solve is not part
+        of the graph (it needs a host read): call match_tensors itself when inputs may be degenerate."""
+        ins = [None if t is None else t.clone() for t in (A_lo, B_lo, A_hi, B_hi)]
+        with torch.inference_mode():
+            for _ in range(warmup):                               # builds every weight cache and library plan eagerly
+                self.match_tensors(*ins)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self.match_tensors(*ins)
+
+        def run(*new):
+            for dst, src in zip(ins, new):
+                if dst is not None and src is not None and src.data_ptr() != dst.data_ptr():
+                    dst.copy_(src)
+            graph.replay()
+            return out
+
+        run.graph, run.static_inputs, run.static_outputs = graph, ins, out
+        return run
 
     @torch.inference_mode()
     def encode(self, im_lo, im_hi=None):

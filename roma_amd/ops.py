@@ -47,7 +47,7 @@ class KernelTimer:
         self.enabled = False
 
     def wrap(self, name, nbytes, tag, launch):
-        if not self.enabled:
+        if not self.enabled or torch.cuda.is_current_stream_capturing():
             return launch()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
@@ -307,8 +307,10 @@ def _raise_if_not_spd(bad):
 
 
 def raise_pending():
-    """Examine the deferred spd_solve checks (RegressionMatcher.match_tensors calls this before it returns: by then the
+    """(No-op while a hipGraph is being captured.)  Examine the deferred spd_solve checks (RegressionMatcher.match_tensors calls this before it returns: by then the
     factorisation finished long ago, so the wait is free)."""
+    if torch.cuda.is_current_stream_capturing():
+        return
     todo, _PENDING[:] = list(_PENDING), []
     for chk in todo:
         _raise_if_not_spd(chk.result())
@@ -442,7 +444,7 @@ def nn_argmin(q, r):
 
 def dwconv5x5_bn_relu(x, w25, scale, shift, out=None):
     """relu(BN(depthwise5x5(x))) with BN folded into (scale, shift) — matcher.py:77-103.  x, out: channels-last
-    (B,C,H,W) views; w25 (25,C) tap-major, fp32 or — for 16-bit x — x's dtype (autocast semantics; the pipelined kernel)."""
+    (B,C,H,W) views; w25 (25,C) fp32 tap-major."""
     _need_gpu(x, w25, scale, shift, out)
     B, C, H, W = x.shape
     lx, px, xx = feat_layout(x)
@@ -453,8 +455,7 @@ def dwconv5x5_bn_relu(x, w25, scale, shift, out=None):
     lo, po, o = feat_layout(out)
     if lo != ROMA_NHWC or o is not out:
         raise ValueError("dwconv5x5_bn_relu needs channels-last output")
-    assert w25.is_contiguous() and w25.shape == (25, C) and w25.dtype in (torch.float32, x.dtype)
-    check(_lib.load().roma_dwconv5x5_bn_relu(_p(xx), _p(w25), _dt(w25), _p(scale), _p(shift), _p(out), B, C, H, W, _dt(xx), px, po, _stream()),
+    check(_lib.load().roma_dwconv5x5_bn_relu(_p(xx), _p(w25), _p(scale), _p(shift), _p(out), B, C, H, W, _dt(xx), px, po, _stream()),
           "roma_dwconv5x5_bn_relu")
     return out
 

@@ -346,6 +346,24 @@ def test_encode_once_match_many(full_model):
     assert maxerr(w_ba[:, :, :W2, 2:], w[:, :, W2:, :2]) < 1e-4           # B->A half of (A,B) == A->B half of (B,A)
 
 
+def test_graphed_step_equals_eager(full_model):
+    """RegressionMatcher.make_graphed: one captured hipGraph (both streams of the step, library and hand-written kernels) replays
+    to exactly what the eager launches produce, also after the static inputs were overwritten with another pair."""
+    from roma_amd.synthetic import synthetic_pair
+    _set_dtype(full_model, torch.float16)
+    try:
+        p0 = [t.to(DEV) for t in synthetic_pair(0, (112, 112), (168, 168))]
+        p1 = [t.to(DEV) for t in synthetic_pair(1, (112, 112), (168, 168))]
+        run = full_model.make_graphed(*p0)
+        for pair in (p0, p1, p0):
+            w, c = run(*pair)
+            we, ce = full_model.match_tensors(*pair)
+            torch.cuda.synchronize()
+            assert torch.equal(w, we) and torch.equal(c, ce)
+    finally:
+        _set_dtype(full_model, torch.float32)
+
+
 def test_match_rejects_bad_images(full_model):
     from PIL import Image
     with pytest.raises(NotImplementedError):

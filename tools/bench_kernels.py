@@ -60,8 +60,6 @@ def main():
     for D, h in [(1384, 40), (1144, 70), (576, 140), (144, 280), (24, 560), (1144, 108), (576, 216), (144, 432), (24, 864)]:
         x = torch.randn(B, D, h, h, device="cuda").to(dt).contiguous(memory_format=torch.channels_last)
         w = torch.randn(25, D, device="cuda")
-        if dt != torch.float32 and os.environ.get("ROMA_DW_TAPS", "16") == "16":
-            w = w.to(dt)                     # autocast semantics: 16-bit taps (the kernel the 16-bit pipeline runs)
         sc, sh = torch.rand(D, device="cuda") + 0.5, torch.randn(D, device="cuda")
         y = torch.empty_like(x)
         t = timeit(lambda: ops.dwconv5x5_bn_relu(x, w, sc, sh, out=y), iters=20)
