@@ -49,7 +49,8 @@ def parse_args(argv=None):
     ap.add_argument("--workload", default="outdoor", choices=["outdoor", "indoor_sample", "tiny"])
     ap.add_argument("--pairs", type=int, default=0, help="image pairs per GPU per step (weak scaling); 0 = the workload's default (1 / 8 / 256)")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16", "fp32"])
-    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--graph", action="store_true", help="replay ONE captured hipGraph per step instead of ~900 eager launches (measured: "
+                    "+0.4 %% — the step is GPU-bound, not launch-bound; the roofline events then come from an eager pass after the timed region)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / parity legs")
     ap.add_argument("--no-microbench", action="store_true", help="skip the standalone local_corr launches (for --pmc passes over the pipeline only)")
     return ap.parse_args(argv)
@@ -255,7 +256,7 @@ def make_workload(args, device, dtype, rank, P):
         A_lo, B_lo, A_hi, B_hi = (torch.cat([p[j] for p in pairs]).to(device) for j in range(4))
         if args.workload == "outdoor":
             graphed = None
-            if not args.no_graph:
+            if args.graph:
                 try:                                              # one hipGraph per step: ~900 launches replayed by one host call
                     graphed = model.make_graphed(A_lo, B_lo, A_hi, B_hi)
                 except Exception as e:                            # noqa: BLE001 — capture is an optimisation, the eager path is the same kernels
