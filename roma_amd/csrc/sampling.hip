@@ -75,38 +75,6 @@ __global__ __launch_bounds__(256) void warp_nhwc_kernel(const T* __restrict__ sr
   }
 }
 
-// channels-last with FEW channels that do not fill 16-byte packets (the scale-1 refiner warps C = 9 channels inside a 24-channel
-// pixel): one thread per output pixel — flow, corner weights and the four tap addresses once per pixel instead of once per
-// element (the generic kernel below spends its time on that redundancy: 70 us vs 15 us for the 64-channel level)
-template <typename T, int CMAX>
-__global__ __launch_bounds__(256) void warp_smallc_kernel(const T* __restrict__ src, const float* __restrict__ flow,
-                                                          T* __restrict__ dst, int B, int C, int Hs, int Ws, int H, int W,
-                                                          int src_pitch, int dst_pitch, int src_shift) {
-  const size_t total = (size_t)B * H * W;
-  for (size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pix < total; pix += (size_t)gridDim.x * blockDim.x) {
-    const int x = (int)(pix % W);
-    const int y = (int)((pix / W) % H);
-    const int b = (int)(pix / ((size_t)W * H));
-    const float fx = flow[((size_t)(b * 2 + 0) * H + y) * W + x];
-    const float fy = flow[((size_t)(b * 2 + 1) * H + y) * W + x];
-    const Corner c = corners(fx, fy, Hs, Ws);
-    const T* base = src + (size_t)((b + src_shift) % B) * Hs * Ws * src_pitch;
-    const int xa = min(max(c.x0, 0), Ws - 1), xb = min(max(c.x0 + 1, 0), Ws - 1);
-    const int ya = min(max(c.y0, 0), Hs - 1), yb = min(max(c.y0 + 1, 0), Hs - 1);
-    const T* p00 = base + ((size_t)ya * Ws + xa) * src_pitch;
-    const T* p01 = base + ((size_t)ya * Ws + xb) * src_pitch;
-    const T* p10 = base + ((size_t)yb * Ws + xa) * src_pitch;
-    const T* p11 = base + ((size_t)yb * Ws + xb) * src_pitch;
-    const float w00 = c.v00 ? c.w00 : 0.f, w01 = c.v01 ? c.w01 : 0.f, w10 = c.v10 ? c.w10 : 0.f, w11 = c.v11 ? c.w11 : 0.f;
-    T* d = dst + pix * dst_pitch;
-#pragma unroll
-    for (int ch = 0; ch < CMAX; ++ch)
-      if (ch < C)
-        d[ch] = from_f32<T>(__builtin_fmaf(w11, to_f32(p11[ch]), __builtin_fmaf(w10, to_f32(p10[ch]),
-                                           __builtin_fmaf(w01, to_f32(p01[ch]), w00 * to_f32(p00[ch])))));
-  }
-}
-
 // any layout combination, scalar accesses; x runs fastest over lanes for planar data, c for channels-last
 template <typename T>
 __global__ __launch_bounds__(256) void warp_generic_kernel(const T* __restrict__ src, const float* __restrict__ flow,
@@ -229,13 +197,9 @@ extern "C" int roma_warp_bilinear(const void* src, const float* flow, void* dst,
   const int e16 = dtype == ROMA_F32 ? 4 : 8;
   const bool vec = layout == ROMA_NHWC && dst_layout == ROMA_NHWC && C % e16 == 0 && src_pitch % e16 == 0 &&
                    dst_pitch % e16 == 0 && aligned16(src) && aligned16(dst);
-  const bool smallc = !vec && layout == ROMA_NHWC && dst_layout == ROMA_NHWC && C <= 16;
-  const size_t total = vec ? (size_t)B * H * W * (C / e16) : smallc ? (size_t)B * H * W : (size_t)B * H * W * C;
+  const size_t total = vec ? (size_t)B * H * W * (C / e16) : (size_t)B * H * W * C;
 #define ROMA_WARP(T)                                                                                                     \
-  if (smallc)                                                                                                            \
-    hipLaunchKernelGGL((warp_smallc_kernel<T, 16>), dim3(grid_for(total)), dim3(256), 0, s, (const T*)src, flow, (T*)dst, B, C, \
-                       Hs, Ws, H, W, src_pitch, dst_pitch, src_batch_shift);                                             \
-  else if (vec)                                                                                                          \
+  if (vec)                                                                                                               \
     hipLaunchKernelGGL((warp_nhwc_kernel<T>), dim3(grid_for(total)), dim3(256), 0, s, (const T*)src, flow, (T*)dst, B, C, Hs, \
                        Ws, H, W, src_pitch, dst_pitch, src_batch_shift);                                                 \
   else                                                                                                                   \
