@@ -4,7 +4,7 @@
 usage: tools/pmc_traffic.py <dir with the FETCH_SIZE pass> <dir with the WRITE_SIZE pass> <algorithmic bytes per launch>
 Corrections per /opt/skills/guides/MI355X_MICROARCH.md: the counters are in KB (1024 B); on gfx950 FETCH_SIZE counts
 128-byte requests as 64 B, so it is doubled.  Counters are summed over XCDs / instances per dispatch by rocprofv3."""
-import csv, glob, json, sys
+import csv, glob, hashlib, json, os, sys
 
 
 def mean_counter(d, name):
@@ -24,7 +24,10 @@ def mean_counter(d, name):
 fetch, n1 = mean_counter(sys.argv[1], "FETCH_SIZE")
 write, n2 = mean_counter(sys.argv[2], "WRITE_SIZE")
 alg = float(sys.argv[3])
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = {
+    # bench.py reports this figure only while local_corr.hip is the file it was collected for
+    "kernel_source_sha1": hashlib.sha1(open(os.path.join(ROOT, "roma_amd", "csrc", "local_corr.hip"), "rb").read()).hexdigest(),
     "hbm_bytes_per_launch": fetch * 1024 * 2 + write * 1024,
     "fetch_size_kb_mean": fetch, "write_size_kb_mean": write, "dispatches": min(n1, n2),
     "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python3 bench.py --no-cpu --no-microbench --steps 3 "
