@@ -51,6 +51,7 @@ def parse_args(argv=None):
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16", "fp32"])
     ap.add_argument("--graph", action="store_true", help="replay ONE captured hipGraph per step instead of ~900 eager launches (measured: "
                     "+0.4 %% — the step is GPU-bound, not launch-bound; the roofline events then come from an eager pass after the timed region)")
+    ap.add_argument("--wire", default="fp32", choices=["fp32", "fp16"], help="dtype of (warp, certainty) on the links of the N>1 gather")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / parity legs")
     ap.add_argument("--no-microbench", action="store_true", help="skip the standalone local_corr launches (for --pmc passes over the pipeline only)")
     return ap.parse_args(argv)
@@ -399,7 +400,7 @@ def main():
             warp, cert = out[0], out[1]
             if backend != "nccl":                       # rehearsal path: gloo gathers host tensors
                 warp, cert = warp.cpu(), cert.cpu()
-            gather_results(warp, cert, world * P, dst=0)
+            gather_results(warp, cert, world * P, dst=0, wire_dtype=torch.float16 if args.wire == "fp16" else None)
         return out
 
     for _ in range(args.warmup):
@@ -494,7 +495,7 @@ def main():
             cpu, parity, parity16 = parity_legs(device, dtype, pin, images)
         total_pairs = world * P * args.steps
         cfg.update(pairs_per_gpu_per_step=P, global_pairs_per_step=world * P,
-                   parallelism=f"pair-sharded x{world}, one ordered gather of (warp, certainty) to rank 0 per step" if world > 1 else "single GPU")
+                   parallelism=f"pair-sharded x{world}, one ordered gather of (warp, certainty) to rank 0 per step ({args.wire} on the links)" if world > 1 else "single GPU")
         cfg.update(extra)
         line = {
             "metric": "image-pairs/sec at 560->864" if args.workload != "tiny" else "image-pairs/sec at 480x640 (tiny_roma_v1)",

@@ -24,13 +24,13 @@ def _fake_match(pairs):
     return w, c
 
 
-def _worker(rank, world, port, npairs, q):
+def _worker(rank, world, port, npairs, q, wire=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from roma_amd.dist import match_sharded, shard_range
         lo, hi = shard_range(npairs, world, rank)
-        warp, cert = match_sharded(_fake_match, list(range(npairs)))
+        warp, cert = match_sharded(_fake_match, list(range(npairs)), wire_dtype=wire)
         if rank == 0:
             q.put((warp.clone(), cert.clone(), (lo, hi)))
         else:
@@ -61,6 +61,27 @@ def test_two_rank_shard_and_gather(npairs):
         assert abs(float(cert[i, 0, 0]) - i / 100.0) < 1e-7
     spans = sorted(r[2] for r in results)
     assert spans[0][0] == 0 and spans[-1][1] == npairs and spans[0][1] == spans[1][0]
+
+
+def test_two_rank_gather_with_fp16_wire_format():
+    """wire_dtype=float16: half the bytes on the links, results back in fp32 on rank 0 and exact for fp16-representable values
+    (pair indices, i/100 rounded to fp16)."""
+    world, npairs = 2, 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, npairs, q, torch.float16)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    warp, cert, _ = next(r for r in results if r[0] is not None)
+    assert warp.dtype == torch.float32 and cert.dtype == torch.float32 and warp.shape == (npairs, 3, 4, 4)
+    for i in range(npairs):
+        assert float(warp[i].min()) == float(warp[i].max()) == float(i)
+        assert abs(float(cert[i, 0, 0]) - i / 100.0) < 5e-4
 
 
 def test_single_process_is_identity():
