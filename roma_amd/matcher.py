@@ -237,7 +237,7 @@ class GP(nn.Module):
         ys = y.float().flatten(2).transpose(1, 2).contiguous()
         K_yy = ops.cos_kernel(ys, ys, T=self.K.T, diag_add=self.sigma_noise)
         K_xy = ops.cos_kernel(xs, ys, T=self.K.T)
-        mu = K_xy @ ops.spd_solve(K_yy, self.basis(1, h2, w2, x.device))
+        mu = self.posterior_product(K_xy, ops.spd_solve(K_yy, self.basis(1, h2, w2, x.device)))
         return mu.transpose(1, 2).reshape(b, self.dim, h1, w1)
 
     def posterior_rows(self, xs, ys, h2, w2, fp64=False, batch_shift=0, out=None, check="now"):
@@ -272,19 +272,28 @@ class GP(nn.Module):
             K_self = ops.cos_kernel(xs, xs, T=self.K.T, diag_add=self.sigma_noise)
             K_xy = ops.cos_kernel(xs, xs, T=self.K.T, batch_shift=s)
             Z = ops.spd_solve(K_self, basis, check=check)            # Z[b] belongs to K_yy of item (b - s) % B
-            if out is None:
-                out = torch.empty((B, n, self.dim), dtype=torch.float32, device=xs.device)
-            if s == 0:
-                torch.bmm(K_xy, Z, out=out)
-            else:
+            if s:
                 assert 2 * s == B, "only the half swap of forward_symmetric"
-                torch.bmm(K_xy[:s], Z[s:], out=out[:s])
-                torch.bmm(K_xy[s:], Z[:s], out=out[s:])
-            return out
-        K_yy = ops.cos_kernel(ys, ys, T=self.K.T, diag_add=self.sigma_noise)
-        K_xy = ops.cos_kernel(xs, ys, T=self.K.T)
-        Z = ops.spd_solve(K_yy, basis, check=check)
-        return torch.bmm(K_xy, Z, out=out) if out is not None else torch.bmm(K_xy, Z)
+                Z = torch.cat((Z[s:], Z[:s]), dim=0)
+        else:
+            K_yy = ops.cos_kernel(ys, ys, T=self.K.T, diag_add=self.sigma_noise)
+            K_xy = ops.cos_kernel(xs, ys, T=self.K.T)
+            Z = ops.spd_solve(K_yy, basis, check=check)
+        return self.posterior_product(K_xy, Z, out)
+
+    @staticmethod
+    def posterior_product(K_xy, Z, out=None):
+        """mu = K_xy @ Z (matcher.py:263) accumulated in fp64.  This product is where the fp32 GP loses its accuracy: 1600 terms
+        of magnitude up to |K||Z| ~ 16 cancel down to |mu| ~ 2, so fp32 ACCUMULATION alone costs 1.9e-3 on mu — measured with
+        exact Z and exactly rounded K_xy (tools/scratch/gp_err.py: fp32-MFMA kernel matrices + fp32 Cholesky + fp32 product
+        2.1e-3, the reference's literal fp32 method on the GPU 1.9e-3, its CPU path 9e-4), while the kernel matrices and the
+        solve contribute ~2e-4 together.  The operands stay the fp32 kernel outputs; only the accumulator is wider (one library
+        fp64 GEMM, 5.2 GFLOP per pair)."""
+        mu = torch.bmm(K_xy.double(), Z.double())
+        if out is None:
+            return mu.float()
+        out.copy_(mu)
+        return out
 
 
 # ------------------------------------------------------------------------------------------------
