@@ -140,6 +140,11 @@ int roma_normalize_u8(const void* in, float* out, int H, int W, const float* mea
  *   x[b,c,:] = max(x[b,c,:] + bias[c], 0) in place on a planar (B,C,HW) map of `dtype`; bias (C) of `dtype`.  B*C <= 65535. */
 int roma_bias_relu_nchw(void* x, const void* bias, int B, int C, int HW, int dtype, void* stream);
 
+/* The same epilogue for the VGG19-BN layers that are followed by MaxPool2d(2, 2) (encoders.py:68-78; the feature is captured before
+ * each pool): x is updated in place as above and pooled[b,c,y,x] = max of the 2x2 block of the result, (B,C,H/2,W/2) of `dtype`.
+ * H and W even. */
+int roma_bias_relu_pool2_nchw(void* x, const void* bias, void* pooled, int B, int C, int H, int W, int dtype, void* stream);
+
 /* ConvRefiner block front half — matcher.py:77-103 (create_block: depthwise 5x5 conv, BatchNorm(eval), ReLU),
  * fused, channels-last.  BN is folded by the caller: y = relu(dwconv(x, w) * scale + shift).
  *   x,y: (B,H,W,pitch) `dtype`; w: (25, C) fp32 tap-major; scale, shift: (C) fp32. */

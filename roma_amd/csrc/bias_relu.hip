@@ -46,10 +46,66 @@ __global__ __launch_bounds__(256) void bias_relu_kernel_f32(float* __restrict__ 
   }
 }
 
+// bias + ReLU in place AND the 2x2 / stride-2 max-pool of the result in the same pass — the VGG19-BN layers that are followed
+// by a pool (encoders.py:68-78: the feature is captured BEFORE each pool, so the full-resolution map is still written; what the
+// fusion removes is the pool kernel's second read of it: 191 MB at 864 x 864 x 64).  One thread = two rows x VEC columns.
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void bias_relu_pool_kernel(T* __restrict__ x, const T* __restrict__ bias, T* __restrict__ pooled,
+                                                            int C, int H, int W) {
+  const int plane = blockIdx.y;                               // b * C + c
+  const float bv = to_f32(bias[plane % C]);
+  T* p = x + (size_t)plane * H * W;
+  T* q = pooled + (size_t)plane * (H / 2) * (W / 2);
+  const int wv = W / VEC, n = (H / 2) * wv;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int yo = i / wv, xv = i - yo * wv;
+    T* r0 = p + (size_t)(2 * yo) * W + xv * VEC;
+    T* r1 = r0 + W;
+    float a[VEC], b[VEC];
+    if constexpr (VEC == 8 && sizeof(T) == 2) {
+      unpack16<T>(*reinterpret_cast<const u32x4*>(r0), a);
+      unpack16<T>(*reinterpret_cast<const u32x4*>(r1), b);
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { a[e] = to_f32(r0[e]); b[e] = to_f32(r1[e]); }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { a[e] = fmaxf(a[e] + bv, 0.f); b[e] = fmaxf(b[e] + bv, 0.f); }
+    if constexpr (VEC == 8 && sizeof(T) == 2) {
+      *reinterpret_cast<u32x4*>(r0) = pack16<T>(a);
+      *reinterpret_cast<u32x4*>(r1) = pack16<T>(b);
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { r0[e] = from_f32<T>(a[e]); r1[e] = from_f32<T>(b[e]); }
+    }
+    T* o = q + (size_t)yo * (W / 2) + xv * (VEC / 2);
+#pragma unroll
+    for (int e = 0; e < VEC / 2; ++e)   // max of values already rounded to T would equal the rounded max: rounding is monotone
+      o[e] = from_f32<T>(fmaxf(fmaxf(a[2 * e], a[2 * e + 1]), fmaxf(b[2 * e], b[2 * e + 1])));
+  }
+}
+
 }  // namespace
 }  // namespace roma
 
 using namespace roma;
+
+extern "C" int roma_bias_relu_pool2_nchw(void* x, const void* bias, void* pooled, int B, int C, int H, int W, int dtype, void* stream) {
+  ROMA_REQUIRE(x && bias && pooled, ROMA_E_ARG, "roma_bias_relu_pool2_nchw: null pointer");
+  ROMA_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && (long)B * C <= 65535 && H % 2 == 0 && W % 2 == 0, ROMA_E_SHAPE,
+               "roma_bias_relu_pool2_nchw: bad shape B=%d C=%d H=%d W=%d (even H, W; B*C <= 65535)", B, C, H, W);
+  ROMA_REQUIRE(dtype >= ROMA_F32 && dtype <= ROMA_BF16, ROMA_E_DTYPE, "roma_bias_relu_pool2_nchw: dtype %d", dtype);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int planes = B * C;
+  auto gridx = [&](int vec) { const int n = ((H / 2) * (W / vec) + 255) / 256; return n < 64 ? n : 64; };
+  const bool v8 = dtype != ROMA_F32 && W % 8 == 0 && aligned16(x);
+#define ROMA_BRP(T, V) hipLaunchKernelGGL((bias_relu_pool_kernel<T, V>), dim3(gridx(V), planes), dim3(256), 0, s, (T*)x, (const T*)bias, (T*)pooled, C, H, W)
+  if (dtype == ROMA_F32) ROMA_BRP(float, 2);
+  else if (dtype == ROMA_F16) { if (v8) ROMA_BRP(half_t, 8); else ROMA_BRP(half_t, 2); }
+  else { if (v8) ROMA_BRP(bf16_t, 8); else ROMA_BRP(bf16_t, 2); }
+#undef ROMA_BRP
+  ROMA_CHECK_LAUNCH();
+}
 
 extern "C" int roma_bias_relu_nchw(void* x, const void* bias, int B, int C, int HW, int dtype, void* stream) {
   ROMA_REQUIRE(x && bias, ROMA_E_ARG, "roma_bias_relu_nchw: null pointer");

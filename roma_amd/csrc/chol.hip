@@ -17,6 +17,7 @@
 //   inverse:      (4) the four 16 x 16 diagonal blocks of L^-1 by forward substitution (one thread per column), then the
 //                     off-diagonal blocks as small products, W21 = -W22 (L21 W11), first inside each 32 x 32 half, then the
 //                     32 x 32 block below the diagonal.
+#include <type_traits>
 #include "common.h"
 
 namespace roma {
@@ -125,25 +126,30 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(float* __restrict__ A, i
   __syncthreads();
   // off-diagonal block (rows r0.., cols c0.., size m) of W = -W22 (L21 W11), W11 / W22 the already finished m x m diagonal
   // blocks at c0 / r0.  Two products through the scratch tile Ts; every thread owns m*m/256 (or fewer) elements.
-  auto offdiag = [&](int r0, int c0, int m) {
-    for (int e = tid; e < m * m; e += 256) {                     // T = L21 W11      (W11 lower triangular: k >= j)
+  // (fixed-length, fully unrolled sums: W11 / W22 are stored with exact zeros above their diagonals, so the triangular bounds are
+  // not needed, and without run-time trip counts hipcc pipelines the LDS reads instead of paying one round trip per term)
+  auto offdiag = [&](int r0, int c0, auto mconst) {
+    constexpr int m = decltype(mconst)::value;
+    for (int e = tid; e < m * m; e += 256) {                     // T = L21 W11
       const int i = e / m, j = e - i * m;
       float acc = 0.f;
-      for (int k = j; k < m; ++k) acc = __builtin_fmaf(Ls[(r0 + i) * LDS_LD + c0 + k], Ws[(c0 + k) * LDS_LD + c0 + j], acc);
+#pragma unroll
+      for (int k = 0; k < m; ++k) acc = __builtin_fmaf(Ls[(r0 + i) * LDS_LD + c0 + k], Ws[(c0 + k) * LDS_LD + c0 + j], acc);
       Ts[i * 33 + j] = acc;
     }
     __syncthreads();
-    for (int e = tid; e < m * m; e += 256) {                     // W21 = -W22 T     (W22 lower triangular: k <= i)
+    for (int e = tid; e < m * m; e += 256) {                     // W21 = -W22 T
       const int i = e / m, j = e - i * m;
       float acc = 0.f;
-      for (int k = 0; k <= i; ++k) acc = __builtin_fmaf(Ws[(r0 + i) * LDS_LD + r0 + k], Ts[k * 33 + j], acc);
+#pragma unroll
+      for (int k = 0; k < m; ++k) acc = __builtin_fmaf(Ws[(r0 + i) * LDS_LD + r0 + k], Ts[k * 33 + j], acc);
       Ws[(r0 + i) * LDS_LD + c0 + j] = -acc;
     }
     __syncthreads();
   };
-  offdiag(PB, 0, PB);                                            // (4b) inside the upper-left 32 x 32 half
-  offdiag(3 * PB, 2 * PB, PB);                                   //      inside the lower-right 32 x 32 half
-  offdiag(2 * PB, 0, 2 * PB);                                    // (4c) the 32 x 32 block below the diagonal
+  offdiag(PB, 0, std::integral_constant<int, PB>{});            // (4b) inside the upper-left 32 x 32 half
+  offdiag(3 * PB, 2 * PB, std::integral_constant<int, PB>{});   //      inside the lower-right 32 x 32 half
+  offdiag(2 * PB, 0, std::integral_constant<int, 2 * PB>{});    // (4c) the 32 x 32 block below the diagonal
 
   // store: L over the lower triangle of the block, W in full (zero above its diagonal)
   for (int e = tid; e < NBMAX * NBMAX; e += 256) {

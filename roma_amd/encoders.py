@@ -65,13 +65,23 @@ class VGG19(nn.Module):
         # gfx950 for this stack (5.7 vs 7.0 ms for the 560 + 864 passes); the decoder's projection GEMM
         # reads the planar maps as its transposed operand and writes channels-last, so no layout pass is needed
         x = x.to(dtype).contiguous()
-        for step in self.fold(dtype):
+        plan = self.fold(dtype)
+        for i, step in enumerate(plan):
             if step is None:
-                feats[scale] = x
-                scale *= 2
-                x = F.max_pool2d(x, 2, 2)
+                continue                                          # the pool was fused into the layer before it (or is the unused last one)
+            pooled_next = i + 1 < len(plan) and plan[i + 1] is None
+            x = F.conv2d(x, step[0], None, padding=1)
+            if not pooled_next:
+                x = ops.bias_relu_(x, step[1])                    # one epilogue pass instead of add_ + relu_
+                continue
+            feats[scale] = x                                      # captured BEFORE the pool (encoders.py:73-76)
+            last = i + 2 >= len(plan)                             # layers[:40] ends on a pool whose output nothing reads
+            if last or x.shape[-1] % 2 or x.shape[-2] % 2:
+                ops.bias_relu_(x, step[1])
+                x = None if last else F.max_pool2d(x, 2, 2)
             else:
-                x = ops.bias_relu_(F.conv2d(x, step[0], None, padding=1), step[1])     # one epilogue pass instead of add_ + relu_
+                x = ops.bias_relu_pool2_(x, step[1])              # bias + ReLU in place and the 2x2 max in the same pass
+            scale *= 2
         return feats
 
 

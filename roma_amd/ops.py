@@ -498,6 +498,21 @@ def bias_relu_(x, bias):
     return x
 
 
+def bias_relu_pool2_(x, bias):
+    """bias_relu_ fused with the following MaxPool2d(2, 2): x (B,C,H,W) planar is updated in place (the pyramid feature captured
+    before the pool, encoders.py:68-78) and the pooled (B,C,H/2,W/2) map is returned."""
+    _need_gpu(x, bias)
+    B, C, H, W = x.shape
+    assert x.is_contiguous() and bias.dtype == x.dtype and bias.numel() == C and bias.is_contiguous() and H % 2 == 0 and W % 2 == 0
+    out = torch.empty((B, C, H // 2, W // 2), dtype=x.dtype, device=x.device)
+    step = max(1, 65535 // C)
+    for b0 in range(0, B, step):
+        xb = x[b0:b0 + step]
+        check(_lib.load().roma_bias_relu_pool2_nchw(_p(xb), _p(bias), _p(out[b0:b0 + step]), xb.shape[0], C, H, W, _dt(x), _stream()),
+              "roma_bias_relu_pool2_nchw")
+    return out
+
+
 def pointwise_mfma(rows, wt, bias, C, out=None):
     """rows (M, pitch) @ wt[:C,:C]^T + bias for 32 < C <= 160 on the matrix cores (matcher.py:102).  wt (kpad,kpad) [out][in] in
     rows' dtype, bias (kpad) fp32; out may be `rows` itself only for a full in-place update of the same rows."""

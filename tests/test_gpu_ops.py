@@ -546,6 +546,19 @@ def test_bias_relu_inplace(shape, dtype):
     assert torch.equal(out, ref)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 64, 56, 40), (1, 128, 140, 140), (3, 5, 6, 10), (1, 3, 4, 2)])
+def test_bias_relu_pool2_inplace(shape, dtype):
+    """bias + ReLU in place and the 2x2 max-pool of the result in one pass == the two library passes (encoders.py:68-78)."""
+    x = H.T(R.normal(f"brp.{shape}", shape), DEV).to(dtype)
+    b = H.T(R.normal(f"brp.b.{shape}", (shape[1],)), DEV).to(dtype)
+    ref = torch.relu(x.float() + b.float().view(1, -1, 1, 1)).to(dtype)
+    xs = x.clone()
+    pooled = _ops().bias_relu_pool2_(xs, b)
+    assert torch.equal(xs, ref)
+    assert torch.equal(pooled, torch.nn.functional.max_pool2d(ref.float(), 2, 2).to(dtype))
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("C,kpad,M", [(144, 160, 4999), (144, 160, 64), (160, 160, 1000), (48, 160, 333), (24, 32, 777)])
 def test_pointwise_mfma_vs_torch(C, kpad, M, dtype):
