@@ -10,6 +10,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libroma_hip.so")
 
 ROMA_F32, ROMA_F16, ROMA_BF16 = 0, 1, 2
 ROMA_NCHW, ROMA_NHWC = 0, 1
+LC_VARIANTS = {"auto": 0, "tile8x4": 1, "tile8x8": 2, "ring": 3}
 ABI_VERSION = 2
 
 # name -> argtypes; restype is c_int unless listed in _RESTYPES.  Mirrors include/roma_hip.h one to one.
@@ -17,7 +18,7 @@ SIGNATURES = {
     "roma_abi_version": [],
     "roma_last_error": [],
     "roma_local_corr": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
-                        c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+                        c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "roma_warp_bilinear": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                            c_int, c_int, c_int, c_int, c_int, c_void_p],
     "roma_disp_emb": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_int, c_void_p],

@@ -29,6 +29,7 @@ struct LCParams {
   int in_nhwc, out_nhwc;
   int tiles_x, tiles_y;
   int f1_shift;  // f1 batch item paired with f0's item b is (b + f1_shift) % B (forward_symmetric: B/2)
+  int variant;   // ROMA_LC_* kernel selection (16-bit channels-last, r <= 3)
   int max_rows;  // LDS capacity in f1 rows (excluding the zero row)
   float scale;   // C^-1/2
 };
@@ -903,15 +904,25 @@ int launch_any(const LCParams& p, hipStream_t s) {
   if (!(p.in_nhwc && p.C % CC == 0)) return launch_lc<T, R>(p, s);
   if constexpr (sizeof(T) == 2) {
     if constexpr (R <= 3) {
-      // persistent loader / consumer kernel (local_corr_ring.hip), ROMA_LC_RING=1; default: the one-tile-per-workgroup kernel
-      static const bool use_ring = [] { const char* e = getenv("ROMA_LC_RING"); return e && e[0] == '1'; }();   // opt-in until it wins
-      if (use_ring && p.C % 32 == 0 && p.C >= kRingMinC) {
+      // Three kernels for this case; `variant` (roma_hip.h) picks one, AUTO by launch size:
+      //   8x4 tiles, one per workgroup (below): 4-5 workgroups per CU hide the per-tile fixed latencies; best on small launches
+      //     and on incoherent flow (its per-pixel-patch path keeps the highest occupancy);
+      //   8x8 tiles, one per workgroup (local_corr_t8.hip): half the fixed cost per pixel, register epilogue, 3.9 instead of 5.2
+      //     staged rows per pixel: 13-20 % faster on coherent flow once the launch fills the chip several times over, slower on
+      //     incoherent flow (3 workgroups per CU) and on launches of a few hundred tiles;
+      //   persistent loader / consumer ring (local_corr_ring.hip): measured slower everywhere (kept as an experiment).
+      const int nt8 = p.B * ((p.H + 7) / 8) * ((p.W + 7) / 8);
+      int v = p.variant;
+      if (v == ROMA_LC_AUTO) v = (p.C % 32 == 0 && nt8 >= 2048) ? ROMA_LC_TILE8X8 : ROMA_LC_TILE8X4;
+      const bool ring_ok = p.C % 32 == 0 && p.C >= kRingMinC;
+      if ((v == ROMA_LC_TILE8X8 && p.C % 32 == 0) || (v == ROMA_LC_RING && ring_ok)) {
         LCRingParams q{};
         q.f0 = p.f0; q.f1 = p.f1; q.flow = p.flow; q.out = p.out;
         q.B = p.B; q.C = p.C; q.H = p.H; q.W = p.W;
         q.f0_pitch = p.f0_pitch; q.f1_pitch = p.f1_pitch; q.out_pitch = p.out_pitch;
         q.out_nhwc = p.out_nhwc; q.f1_shift = p.f1_shift; q.scale = p.scale;
-        return local_corr_ring(q, R, std::is_same<T, half_t>::value ? ROMA_F16 : ROMA_BF16, s);
+        const int dt = std::is_same<T, half_t>::value ? ROMA_F16 : ROMA_BF16;
+        return v == ROMA_LC_TILE8X8 ? local_corr_t8(q, R, dt, s) : local_corr_ring(q, R, dt, s);
       }
     }
     return launch_lc_mfma<T, R>(p, s);
@@ -940,12 +951,13 @@ int dispatch_r(const LCParams& p, int r, hipStream_t s) {
 
 extern "C" int roma_local_corr(const void* f0, const void* f1, const float* flow, void* out, int B, int C, int H, int W,
                                int r, int dtype, int layout, int f0_pitch, int f1_pitch, int out_layout, int out_pitch,
-                               int f1_batch_shift, void* stream) {
+                               int f1_batch_shift, int variant, void* stream) {
   using namespace roma;
   ROMA_REQUIRE(f0 && f1 && out, ROMA_E_ARG, "roma_local_corr: null pointer");
   ROMA_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, ROMA_E_SHAPE, "roma_local_corr: bad shape B=%d C=%d H=%d W=%d", B, C, H, W);
   ROMA_REQUIRE(r >= 1 && r <= 7, ROMA_E_UNSUPPORTED, "roma_local_corr: radius %d outside 1..7", r);
   ROMA_REQUIRE(f1_batch_shift >= 0 && f1_batch_shift < B, ROMA_E_ARG, "roma_local_corr: f1_batch_shift %d outside [0, B)", f1_batch_shift);
+  ROMA_REQUIRE(variant >= ROMA_LC_AUTO && variant <= ROMA_LC_RING, ROMA_E_ARG, "roma_local_corr: unknown kernel variant %d", variant);
   ROMA_REQUIRE(layout == ROMA_NCHW || layout == ROMA_NHWC, ROMA_E_ARG, "roma_local_corr: bad layout %d", layout);
   ROMA_REQUIRE(out_layout == ROMA_NCHW || out_layout == ROMA_NHWC, ROMA_E_ARG, "roma_local_corr: bad out_layout %d", out_layout);
   const int K = (2 * r + 1) * (2 * r + 1);
@@ -964,6 +976,7 @@ extern "C" int roma_local_corr(const void* f0, const void* f1, const float* flow
   p.in_nhwc = layout == ROMA_NHWC; p.out_nhwc = out_layout == ROMA_NHWC;
   p.scale = 1.0f / sqrtf((float)C);
   p.f1_shift = f1_batch_shift;
+  p.variant = variant;
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (dtype) {
     case ROMA_F32: return dispatch_r<float>(p, r, s);

@@ -21,5 +21,7 @@ struct LCRingParams {
 // 16-bit channels-last inputs, r in 1..3, C a multiple of 32 and >= kRingMinC
 constexpr int kRingMinC = 224;
 int local_corr_ring(const LCRingParams& p, int r, int dtype, hipStream_t stream);
+// one 8x8 tile per workgroup (local_corr_t8.hip): 16-bit channels-last inputs, r in 1..3, C a multiple of 32
+int local_corr_t8(const LCRingParams& p, int r, int dtype, hipStream_t stream);
 
 }  // namespace roma

@@ -130,10 +130,11 @@ def nhwc_empty(B, C, H, W, dtype, device, pitch=None):
 
 
 def local_correlation(feature0, feature1, local_radius, padding_mode="zeros", flow=None, sample_mode="bilinear", out=None,
-                      batch_shift=0):
+                      batch_shift=0, variant="auto"):
     """romatch/utils/local_correlation.py:4-48.  Returns (B,(2r+1)^2,h,w) in feature0's dtype and memory format
     (or fills `out`, e.g. a channel slice of the refiner's channels-last concat buffer).  batch_shift: feature0[b] meets
-    feature1[(b + batch_shift) % B] (forward_symmetric passes the same map twice with batch_shift = B/2)."""
+    feature1[(b + batch_shift) % B] (forward_symmetric passes the same map twice with batch_shift = B/2).  variant: "auto" or
+    one of "tile8x4" / "tile8x8" / "ring" — the three kernels for 16-bit channels-last inputs with r <= 3 (roma_hip.h)."""
     if padding_mode != "zeros" or sample_mode != "bilinear":
         raise NotImplementedError("only padding_mode='zeros', sample_mode='bilinear' (the modes RoMa uses)")
     _need_gpu(feature0, feature1, flow, out)
@@ -162,7 +163,7 @@ def local_correlation(feature0, feature1, local_radius, padding_mode="zeros", fl
     nbytes = 2 * B * C * H * W * es + B * 2 * H * W * 4 + B * K * H * W * es
     TIMER.wrap("local_corr", nbytes, f"C{C}_h{H}x{W}_r{r}",
                lambda: check(_lib.load().roma_local_corr(_p(f0), _p(f1), _p(flow), _p(out), B, C, H, W, r, _dt(f0), l0, p0, p1,
-                                                         lo, po, int(batch_shift) % B, _stream()), "roma_local_corr"))
+                                                         lo, po, int(batch_shift) % B, _lib.LC_VARIANTS[variant], _stream()), "roma_local_corr"))
     return out
 
 

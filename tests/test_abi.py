@@ -32,7 +32,7 @@ def test_version_and_error_string():
 
 def test_argument_validation_needs_no_gpu():
     lib = _lib.load()
-    rc = lib.roma_local_corr(None, None, None, None, 1, 8, 4, 4, 2, 0, 0, 8, 8, 0, 25, 0, None)
+    rc = lib.roma_local_corr(None, None, None, None, 1, 8, 4, 4, 2, 0, 0, 8, 8, 0, 25, 0, 0, None)
     assert rc == -1 and b"null pointer" in lib.roma_last_error()
     rc = lib.roma_kde_density(None, None, 0, 1, 0.1, 0, None)
     assert rc < 0

@@ -121,6 +121,38 @@ def test_local_corr_matrix_core_path_vs_fp32_kernel(shape, kind, dtype):
     assert maxerr(out, ref) <= tol
 
 
+@pytest.mark.parametrize("variant", ["tile8x4", "tile8x8", "ring"])
+@pytest.mark.parametrize("shape", [(1, 512, 70, 70, 3), (1, 256, 140, 140, 2), (2, 256, 37, 53, 1), (1, 64, 37, 53, 2), (2, 32, 21, 18, 3)])
+@pytest.mark.parametrize("kind", ["coherent", "adversarial", "mixed"])
+def test_local_corr_kernel_variants_agree(shape, kind, variant):
+    """The three kernels for 16-bit channels-last inputs with r <= 3 (roma_hip.h: ROMA_LC_*) against the fp32 kernel on the same
+    rounded inputs, partial border tiles, NaN / far-out-of-range flow entries included.  (A variant that does not apply to a shape
+    — the ring needs C >= 224 — falls back inside the library; the call must still be correct.)"""
+    B, C, h, w, r = shape
+    ops = _ops()
+    f0 = H.T(R.normal(f"lcv.{shape}.f0", (B, C, h, w))).half()
+    f1 = H.T(R.normal(f"lcv.{shape}.f1", (B, C, h, w))).half()
+    flow = R.coherent_flow(f"lcv.{shape}.flow", B, h, w)
+    if kind == "adversarial":
+        flow = R.adversarial_flow(f"lcv.{shape}.flow", B, h, w)
+    elif kind == "mixed":
+        adv = R.adversarial_flow(f"lcv.{shape}.adv", B, h, w)
+        flow[:, :, h // 3: 2 * h // 3, w // 4: w // 2] = adv[:, :, h // 3: 2 * h // 3, w // 4: w // 2]
+        flow[:, 0, 0, 0] = float("nan")
+        flow[:, 1, -1, -1] = 1e30
+        flow[:, :, 1, 2] = -7.0
+    flow = H.T(flow, DEV)
+    a16 = f0.to(DEV).contiguous(memory_format=torch.channels_last)
+    b16 = f1.to(DEV).contiguous(memory_format=torch.channels_last)
+    out = ops.local_correlation(a16, b16, r, flow=flow, variant=variant)
+    ref = ops.local_correlation(a16.float().contiguous(memory_format=torch.channels_last),
+                                b16.float().contiguous(memory_format=torch.channels_last), r, flow=flow)
+    assert torch.isfinite(out.float()).all()
+    assert maxerr(out, ref) <= 2 ** -10 * max(1.0, float(ref.abs().max()))
+    planar = ops.local_correlation(a16, b16, r, flow=flow, variant=variant, out=torch.empty(out.shape, dtype=out.dtype, device=DEV))
+    assert maxerr(planar, ref) <= 2 ** -10 * max(1.0, float(ref.abs().max()))          # NCHW output path
+
+
 def test_local_corr_full_size_golden_l16():
     g = H.golden("local_corr")
     B, C, h, w, r = 2, 512, 40, 40, 7

@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=1)
     ap.add_argument("--dtype", default="f16")
     ap.add_argument("--flow", default="coherent")
+    ap.add_argument("--variant", default="auto", help="local_corr kernel: auto | tile8x4 | tile8x8 | ring")
     args = ap.parse_args()
     dt = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[args.dtype]
     es = 4 if dt == torch.float32 else 2
@@ -48,7 +49,7 @@ def main():
         else:
             flow = torch.from_numpy(R.adversarial_flow("bench", B, h, h)).cuda()
         out = ops.nhwc_empty(B, K, h, h, dt, "cuda")
-        t = timeit(lambda: ops.local_correlation(f0, f1, r, flow=flow, out=out))
+        t = timeit(lambda: ops.local_correlation(f0, f1, r, flow=flow, out=out, variant=args.variant))
         nbytes = 2 * B * C * h * h * es + B * 2 * h * h * 4 + B * K * h * h * es
         tot_b += nbytes
         tot_t += t
