@@ -226,7 +226,8 @@ def local_corr_microbench(device, dtype, pairs, iters=20):
             tot_t += t
         out[kind] = {"achieved": tot_b / tot_t / 1e9, "frac": tot_b / tot_t / HBM_PEAK, "unit": "GB/s", "B": B, "per_shape": per}
         del f0, f1, o, flow
-    out["note"] = "standalone launches of local_corr_kernel on the 5 call shapes (B = 2 x pairs per launch), same process, after the timed region"
+    out["note"] = ("standalone launches of roma_local_corr on the 5 call shapes (B = 2 x pairs per launch), same process, after the timed "
+                   "region; kernel variant AUTO: 8x8-pixel tiles for launches of >= 2048 tiles (the 16-pair rows), 8x4 tiles otherwise")
     return out
 
 
