@@ -231,19 +231,26 @@ def local_corr_microbench(device, dtype, pairs, iters=20):
     return out
 
 
+LOCAL_CORR_SOURCES = ("local_corr.hip", "local_corr_t8.hip", "local_corr_ring.hip", "local_corr_ring.h", "lc_device.h")
+
+
 def kernel_source_sha1():
-    return hashlib.sha1(open(os.path.join(ROOT, "roma_amd", "csrc", "local_corr.hip"), "rb").read()).hexdigest()
+    """One digest over every source file of roma_local_corr (dispatch + the three kernels + their shared device header)."""
+    h = hashlib.sha1()
+    for f in LOCAL_CORR_SOURCES:
+        h.update(open(os.path.join(ROOT, "roma_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
 
 
 def measured_traffic():
     """HBM bytes per launch from the separate rocprofv3 --pmc passes (profiles/local_corr_traffic.json, tools/pmc_traffic.py).
-    Only trusted when it was collected for the local_corr.hip this run executes (sha1 stamp); else null + a note."""
+    Only trusted when it was collected for the local_corr sources this run executes (sha1 stamp); else null + a note."""
     pmc = os.path.join(ROOT, "profiles", "local_corr_traffic.json")
     if not os.path.exists(pmc):
         return None, "no profiles/local_corr_traffic.json"
     d = json.load(open(pmc))
     if d.get("kernel_source_sha1") != kernel_source_sha1():
-        return None, "profiles/local_corr_traffic.json was collected for a different local_corr.hip (sha1 mismatch): stale, not reported"
+        return None, "profiles/local_corr_traffic.json was collected for different local_corr sources (sha1 mismatch): stale, not reported"
     return d.get("hbm_bytes_per_launch"), f"rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes, {d.get('dispatches')} dispatches (profiles/local_corr_traffic.json)"
 
 

@@ -6,6 +6,7 @@
 // Row-major logits (class stride 1, the layout `to_out` produces): one wavefront per pixel, 64 lanes stride the
 // classes (coalesced), wave reductions for max / arg-max.  Planar logits (the reference's (B,C,H,W)): one lane per
 // pixel, lanes run along pixels (coalesced), a serial class loop.
+#include <type_traits>
 #include "common.h"
 
 namespace roma {
@@ -68,6 +69,79 @@ __global__ __launch_bounds__(256) void cls_rows_kernel(const T* __restrict__ log
   }
 }
 
+// 16-bit rows, C <= kVecMaxC: ONE pass over HBM with 16-byte loads.  A row of C+1 two-byte logits starts at an arbitrary even
+// address (4097 elements per pixel: 8194-byte pitch), so the wave reads the 16-byte-ALIGNED packets that cover the row —
+// packet pk holds elements 8 pk - h .. 8 pk - h + 7, h = elements between the aligned address below the row and the row — keeps
+// them in registers (9 packets per lane cover 4608 elements), and takes max, exp and arg-max from there.  The two boundary
+// packets are read element by element under a guard: nothing outside [row, row + C) is touched.
+constexpr int kVecPk = 9, kVecMaxC = kVecPk * 64 * 8 - 8;
+
+template <typename T>
+__global__ __launch_bounds__(256) void cls_rows_vec_kernel(const T* __restrict__ logits, float* __restrict__ flow,
+                                                           float* __restrict__ cert, int B, int C, int HW, int res, long sb, long sp) {
+  static_assert(sizeof(T) == 2, "16-bit rows only");
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwave = (gridDim.x * blockDim.x) >> 6;
+  const unsigned short ninf = std::is_same<T, half_t>::value ? 0xFC00u : 0xFF80u;      // -inf in fp16 / bf16
+  for (int pix = wave; pix < B * HW; pix += nwave) {
+    const int b = pix / HW, p = pix - b * HW;
+    const T* row = logits + b * sb + p * sp;
+    const int h = (int)((reinterpret_cast<uintptr_t>(row) & 15) >> 1);
+    const unsigned short* a0 = reinterpret_cast<const unsigned short*>(row) - h;       // 16-byte aligned
+    const int npk = (C + h + 7) >> 3;
+    union Pk { uint4 q; unsigned short u[8]; } v[kVecPk];
+#pragma unroll
+    for (int k = 0; k < kVecPk; ++k) {
+      const int pk = lane + 64 * k, e0 = pk * 8 - h;
+      if (pk < npk && e0 >= 0 && e0 + 8 <= C) {
+        v[k].q = *reinterpret_cast<const uint4*>(a0 + (size_t)pk * 8);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int c = e0 + j;
+          v[k].u[j] = (pk < npk && c >= 0 && c < C) ? a0[(size_t)pk * 8 + j] : ninf;
+        }
+      }
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < kVecPk; ++k)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) m = fmaxf(m, to_f32(__builtin_bit_cast(T, v[k].u[j])));
+    m = wave_max(m);
+    float best = -1.f;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < kVecPk; ++k) {
+      const int e0 = (lane + 64 * k) * 8 - h;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = e0 + j;
+        const float e = expf(to_f32(__builtin_bit_cast(T, v[k].u[j])) - m);
+        if (c >= 0 && c < C && e > best) { best = e; bi = c; }                          // ascending c within the lane
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ob = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) {
+      float e[5];
+      const int idx[5] = {bi - 1, bi, bi + 1, bi - res, bi + res};
+#pragma unroll
+      for (int j = 0; j < 5; ++j) e[j] = expf(ld(row, min(max(idx[j], 0), C - 1)) - m);
+      float fx, fy;
+      refine5(e, bi, C, res, fx, fy);
+      flow[((size_t)b * 2 + 0) * HW + p] = fx;
+      flow[((size_t)b * 2 + 1) * HW + p] = fy;
+      if (cert) cert[(size_t)b * HW + p] = ld(row, C);
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void cls_planar_kernel(const T* __restrict__ logits, float* __restrict__ flow,
                                                          float* __restrict__ cert, int B, int C, int HW, int res, long sb, long sc,
@@ -109,6 +183,16 @@ extern "C" int roma_cls_to_flow_refine(const void* logits, float* flow_out, floa
   ROMA_REQUIRE(dtype >= ROMA_F32 && dtype <= ROMA_BF16, ROMA_E_DTYPE, "roma_cls_to_flow_refine: unknown dtype %d", dtype);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int npix = B * HW;
+  const dim3 rgrid((npix + 3) / 4 > 4096 ? 4096 : (npix + 3) / 4);
+  if (stride_c == 1 && dtype != ROMA_F32 && C <= kVecMaxC) {        // 16-bit rows: one pass, 16-byte loads
+    if (dtype == ROMA_F16)
+      hipLaunchKernelGGL((cls_rows_vec_kernel<half_t>), rgrid, dim3(256), 0, s, (const half_t*)logits, flow_out, cert_out, B, C, HW, res,
+                         stride_b, stride_p);
+    else
+      hipLaunchKernelGGL((cls_rows_vec_kernel<bf16_t>), rgrid, dim3(256), 0, s, (const bf16_t*)logits, flow_out, cert_out, B, C, HW, res,
+                         stride_b, stride_p);
+    ROMA_CHECK_LAUNCH();
+  }
 #define ROMA_CLS(T)                                                                                                            \
   if (stride_c == 1)                                                                                                           \
     hipLaunchKernelGGL((cls_rows_kernel<T>), dim3((npix + 3) / 4 > 4096 ? 4096 : (npix + 3) / 4), dim3(256), 0, s, (const T*)logits, \

@@ -24,7 +24,12 @@ __global__ __launch_bounds__(256, MINW) void dwconv5x5_kernel(const T* __restric
   const int PK = C / E;
   const int WS = (W + XS - 1) / XS, HS = (H + YS - 1) / YS;
   const size_t total = (size_t)B * HS * WS * PK;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+  // XCD-aware block order: the dispatcher deals consecutive workgroups round-robin to the 8 XCDs, so in launch order the strip
+  // below a strip (same columns, next row: 4 of its 5 input rows are the same) lands on another XCD's L2 and the rows are
+  // fetched over the fabric again — rocprofv3 FETCH_SIZE: 2.8x the input at C = 576, 216 x 216.  With the remap every XCD walks
+  // a contiguous band of rows and the halo rows stay in its own L2 (reuse distance: one image row, 0.25 MB).
+  const size_t wid = (size_t)xcd_remap(blockIdx.x, gridDim.x);
+  for (size_t i = wid * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int k = (int)(i % PK);
     size_t r = i / PK;
     const int xs = (int)(r % WS) * XS; r /= WS;

@@ -266,9 +266,32 @@ def test_cls_to_flow_refine_full_size_fp16():
     O = _O()
     x = (H.T(R.normal("clsfull", (2, 4096, 40, 40))) * 3).half()
     ref = O.cls_to_flow_refine(x.float())
-    rows = torch.cat((x.permute(0, 2, 3, 1).reshape(2, 1600, 4096), torch.zeros(2, 1600, 1, dtype=torch.half)), dim=2).to(DEV)
-    flow, _ = _ops().cls_rows_to_flow(rows, 2, 40, 40)
+    clog = H.T(R.normal("clsfull.cert", (2, 1600, 1))).half()
+    rows = torch.cat((x.permute(0, 2, 3, 1).reshape(2, 1600, 4096), clog), dim=2).to(DEV)   # 8194-byte rows: every 16-byte phase occurs
+    flow, cert = _ops().cls_rows_to_flow(rows, 2, 40, 40)
     assert maxerr(flow.permute(0, 2, 3, 1), ref) < 1e-5
+    assert torch.equal(cert.flatten().cpu(), clog.float().flatten())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("res,pad", [(8, 0), (8, 3), (24, 0), (67, 5)])
+def test_cls_rows_16bit_vector_path_shapes(dtype, res, pad):
+    """The one-pass 16-byte-load kernel on rows whose pitch / start are not 16-byte multiples (boundary packets are read under a
+    guard), small and odd class counts (res = 67: 4489 classes, 9 packets on some lanes), arg-max at the first / last class."""
+    O = _O()
+    C, hw = res * res, 35
+    x = (H.T(R.normal(f"clsvec.{res}", (1, C, 5, 7))) * 3).to(dtype)
+    x[0, 0, 0, 0] = 30.0                                        # mode = class 0 (mode-1 clamps)
+    x[0, C - 1, 0, 1] = 30.0                                    # mode = last class (mode+1 clamps)
+    ref = O.cls_to_flow_refine(x.float())
+    buf = torch.zeros(hw * (C + 1 + pad) + 8, dtype=dtype, device=DEV)
+    for off in (0, 1, 5):                                       # row 0 starts 0 / 2 / 10 bytes past a 16-byte boundary
+        rows = buf[off:off + hw * (C + 1 + pad)].view(1, hw, C + 1 + pad)[:, :, :C + 1]
+        rows[..., :C] = x.permute(0, 2, 3, 1).reshape(1, hw, C).to(DEV)
+        rows[..., C] = 0.5
+        flow, cert = _ops().cls_rows_to_flow(rows, 1, 5, 7)
+        assert maxerr(flow.permute(0, 2, 3, 1), ref) < 1e-5
+        assert float((cert - 0.5).abs().max()) == 0.0
 
 
 # ---- CosKernel (MFMA) --------------------------------------------------------------------------

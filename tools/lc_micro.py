@@ -12,6 +12,7 @@ ap.add_argument("--pairs", type=int, default=1)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--flow", default="coherent")
 ap.add_argument("--dtype", default="f16")
+ap.add_argument("--variant", default="auto", choices=["auto", "tile8x4", "tile8x8", "ring"])
 a = ap.parse_args()
 C, h, r = SH[a.shape]
 dt = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[a.dtype]
@@ -21,6 +22,6 @@ f1 = torch.randn(B, C, h, h, device="cuda").to(dt).contiguous(memory_format=torc
 flow = torch.from_numpy(R.coherent_flow("bench", B, h, h) if a.flow == "coherent" else R.adversarial_flow("bench", B, h, h)).cuda()
 out = ops.nhwc_empty(B, (2 * r + 1) ** 2, h, h, dt, "cuda")
 for _ in range(a.iters):
-    ops.local_correlation(f0, f1, r, flow=flow, out=out)
+    ops.local_correlation(f0, f1, r, flow=flow, out=out, variant=a.variant)
 torch.cuda.synchronize()
 print("done", a.shape, B)

@@ -6,6 +6,8 @@ Corrections per /opt/skills/guides/MI355X_MICROARCH.md: the counters are in KB (
 128-byte requests as 64 B, so it is doubled.  Counters are summed over XCDs / instances per dispatch by rocprofv3."""
 import csv, glob, hashlib, json, os, sys
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def mean_counter(d, name):
     files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
@@ -21,13 +23,20 @@ def mean_counter(d, name):
     return sum(vals.values()) / len(vals), len(vals)
 
 
+def source_sha1():
+    """Same digest as bench.py's kernel_source_sha1(): all source files of roma_local_corr."""
+    h = hashlib.sha1()
+    for f in ("local_corr.hip", "local_corr_t8.hip", "local_corr_ring.hip", "local_corr_ring.h", "lc_device.h"):
+        h.update(open(os.path.join(ROOT, "roma_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
+
+
 fetch, n1 = mean_counter(sys.argv[1], "FETCH_SIZE")
 write, n2 = mean_counter(sys.argv[2], "WRITE_SIZE")
 alg = float(sys.argv[3])
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = {
     # bench.py reports this figure only while local_corr.hip is the file it was collected for
-    "kernel_source_sha1": hashlib.sha1(open(os.path.join(ROOT, "roma_amd", "csrc", "local_corr.hip"), "rb").read()).hexdigest(),
+    "kernel_source_sha1": source_sha1(),
     "hbm_bytes_per_launch": fetch * 1024 * 2 + write * 1024,
     "fetch_size_kb_mean": fetch, "write_size_kb_mean": write, "dispatches": min(n1, n2),
     "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python3 bench.py --no-cpu --no-microbench --steps 3 "
