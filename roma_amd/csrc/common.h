@@ -147,6 +147,15 @@ template <> __device__ __forceinline__ u32x4 pack16<bf16_t>(const float* f) {
   return v;
 }
 
+// 16-byte store that does NOT keep its line in the XCD's L2 (sc1: write-through, line dropped — MI355X_MICROARCH.md, store
+// flavours).  For streaming outputs of kernels whose INPUT reuse lives in the L2: a plain store leaves every output line resident
+// and halves the capacity left for the halo rows.
+__device__ __forceinline__ void store16_stream(void* p, const u32x4& v) {
+  // the s_nop: a VALU write to the data registers of a > 64-bit VMEM store needs wait states after it; hipcc inserts them behind its
+  // own stores but cannot see into an asm statement (without it: dword 0 of ~2 % of the packets was the NEXT packet's)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+}
+
 // ATen upsample_bilinear2d, align_corners=False: src = max((dst+0.5)*in/out-0.5, 0)
 __device__ __forceinline__ void interp_src(int d, int in, int out, int& i0, int& i1, float& l1) {
   const float scale = (float)in / (float)out;

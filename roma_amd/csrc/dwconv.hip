@@ -6,7 +6,9 @@
 // XS output pixels along W, streams the (XS+4) input columns of each of the 5 rows through registers once and
 // reuses every loaded packet for up to 5 taps x XS outputs; fp32 accumulation.  Lanes run along the channel
 // packets, so a wavefront's loads are 1 KiB contiguous for C >= 512 (fp16).
+#include <atomic>
 #include <cstdlib>
+#include <type_traits>
 #include "common.h"
 
 namespace roma {
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(256, MINW) void dwconv5x5_kernel(const T* __restric
         float v[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) v[e] = fmaxf(__builtin_fmaf(acc[oy][o][e], sc[e], sh[e]), 0.f);
-        *reinterpret_cast<u32x4*>(yrow + (size_t)(xs + o) * y_pitch) = pack16<T>(v);
+        store16_stream(yrow + (size_t)(xs + o) * y_pitch, pack16<T>(v));
       }
     }
   }
@@ -121,6 +123,170 @@ void launch_dw(const void* x, const float* w, const float* scale, const float* s
   size_t g = (total + 255) / 256;
   if (g > 32768) g = 32768;
   hipLaunchKernelGGL((dwconv5x5_kernel<T, XS, YS, MINW>), dim3((int)g), dim3(256), 0, s, (const T*)x, w, scale, shift, (T*)y, B, C, H, W, x_pitch, y_pitch);
+}
+
+
+// ---- persistent variant, 16-bit activations (round 2) ------------------------------------------------------------------------
+// What rocprofv3 says about the kernel above at C = 576, 216 x 216, B = 2 (profiles/r02_dwconv_pmc.md): the vector ALU is busy 54 %
+// of the time, the L1 moves 1.44 GB (37 us of its 64 B/clk) of which 45 % are the 25 x C fp32 TAPS re-read by every thread for every
+// row, the index decode is 64-bit division, and a wave issues a row's loads and then waits for them (1.5 waves per SIMD on average,
+// no load in flight while it computes).  This variant: the taps live in LDS (one copy per persistent workgroup, read with
+// ds_read_b128 beside the L1 traffic), 32-bit index arithmetic, and the NEXT input row is in flight while the current one is
+// multiplied (a column's registers are refilled with the next row as soon as the column is converted; the row loop stays rolled so
+// hipcc cannot hoist all five rows' loads).  Every
+// XCD walks its own contiguous band of the (b, y, strip, packet) index space, so the halo rows of vertically adjacent strips stay
+// in one L2, and the outputs are stored write-through (sc1) so that they do not occupy that L2.
+template <typename T, int NT>
+__global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void dwconv5x5_lds_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           T* __restrict__ y, int B, int C, int H, int W, int x_pitch, int y_pitch,
+                                                           unsigned total, unsigned band) {
+  constexpr int E = 8, XS = 8, NC = XS + 4;
+  static_assert(sizeof(T) == 2, "16-bit activations");
+  extern __shared__ __attribute__((aligned(16))) float s_w[];     // [25][C]
+  const int tid = threadIdx.x;
+  {                                                               // taps -> LDS, 8 loads in flight per thread (one load per round
+    constexpr int SB = 8;                                         // trip would pay a full L2 latency 14-36 times)
+    const int n4 = 25 * C / 4;
+    for (int e0 = tid; e0 < n4; e0 += NT * SB) {
+      float4_t t[SB];
+#pragma unroll
+      for (int j = 0; j < SB; ++j) t[j] = reinterpret_cast<const float4_t*>(w)[min(e0 + j * NT, n4 - 1)];
+#pragma unroll
+      for (int j = 0; j < SB; ++j)
+        if (e0 + j * NT < n4) reinterpret_cast<float4_t*>(s_w)[e0 + j * NT] = t[j];
+    }
+  }
+  __syncthreads();
+  const unsigned PK = (unsigned)C / E, WS = (unsigned)(W + XS - 1) / XS;
+  // work order: XCD x (the dispatcher deals workgroup b to XCD b % 8) owns the contiguous eighth `band` of the index space, and its
+  // gridDim/8 workgroups walk that band together, NT items each per step — 8 rows of a 216-pixel map per step, so the halo rows
+  // of a step are the L2-resident rows of the step before.  (Contiguous per-workgroup chunks instead had every workgroup of an
+  // XCD miss on the same halo rows at the same time: FETCH_SIZE 5.8x the input.)
+  const unsigned nx = gridDim.x >> 3;
+  const unsigned beg = (blockIdx.x & 7u) * band;
+  const unsigned end = min(beg + band, total);
+  for (unsigned i = beg + (blockIdx.x >> 3) * NT + tid; i < end; i += nx * NT) {
+    const unsigned k = i % PK;
+    unsigned r = i / PK;
+    const int xs = (int)(r % WS) * XS;
+    r /= WS;
+    const int ys = (int)(r % (unsigned)H), b = (int)(r / (unsigned)H);
+    const int c0 = (int)k * E;
+    float acc[XS][E];
+#pragma unroll
+    for (int o = 0; o < XS; ++o)
+#pragma unroll
+      for (int e = 0; e < E; ++e) acc[o][e] = 0.f;
+    const bool interior = ys >= 2 && ys + 3 <= H && xs >= 2 && xs + XS + 2 <= W;
+    // 5 taps x 8 channels of fused multiply-adds for every column of one input row (taps of tap-row iy from LDS)
+    auto fma_row = [&](const u32x4 (&src)[NC], int iy, auto masked_c) {
+      const int yi = ys + iy - 2;
+      const float my = (yi >= 0 && yi < H) ? 1.f : 0.f;
+      const float* wr = s_w + (size_t)iy * 5 * C + c0;
+      float wv[5][E];
+#pragma unroll
+      for (int dx = 0; dx < 5; ++dx)
+#pragma unroll
+        for (int e = 0; e < E; e += 4) *reinterpret_cast<float4_t*>(&wv[dx][e]) = *reinterpret_cast<const float4_t*>(wr + dx * C + e);
+#pragma unroll
+      for (int cx = 0; cx < NC; ++cx) {
+        float f[E];
+        unpack16<T>(src[cx], f);
+        if constexpr (decltype(masked_c)::value) {
+          const int xi = xs - 2 + cx;
+          const float m = (xi >= 0 && xi < W) ? my : 0.f;
+#pragma unroll
+          for (int e = 0; e < E; ++e) f[e] *= m;
+        }
+#pragma unroll
+        for (int dx = 0; dx < 5; ++dx) {
+          const int o = cx - dx;
+          if (o >= 0 && o < XS) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) acc[o][e] = __builtin_fmaf(wv[dx][e], f[e], acc[o][e]);
+          }
+        }
+      }
+    };
+    if (__all(interior)) {                                         // wave-uniform: a wave with one border strip takes the border path whole
+      // all but a 2-pixel frame.  Byte offset of (b, row, column xs - 2, packet k) from x in 32 bits (the host checks the tensor is
+      // < 4 GB); the 12 columns of a row are the uniform distances cx * x_pitch * 2 from it: a load is scalar base + one vector
+      // offset.  Software pipeline: row iy + 1 is requested before row iy is multiplied.  (hipcc converts the whole row to fp32
+      // first — 96 registers — and then issues the 12 loads back to back; pinning a finer interleave needs more registers, not fewer.)
+      unsigned voff = (unsigned)((((size_t)b * H + ys - 2) * W + xs - 2) * x_pitch + c0) * 2u;
+      const unsigned vstep = (unsigned)W * x_pitch * 2u;
+      auto load_row = [&](u32x4 (&dst)[NC]) {
+#pragma unroll
+        for (int cx = 0; cx < NC; ++cx)
+          dst[cx] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(x) + (size_t)cx * x_pitch * 2 + voff);
+        voff += vstep;
+      };
+      u32x4 cur[NC], nxt[NC];
+      load_row(nxt);
+#pragma unroll 1
+      for (int iy = 0; iy < 4; ++iy) {
+#pragma unroll
+        for (int cx = 0; cx < NC; ++cx) cur[cx] = nxt[cx];
+        load_row(nxt);
+        fma_row(cur, iy, std::false_type{});
+      }
+      fma_row(nxt, 4, std::false_type{});
+    } else {
+      // border strips: clamped addresses, taps zeroed through a mask, one row at a time
+#pragma unroll 1
+      for (int iy = 0; iy < 5; ++iy) {
+        const T* row = x + ((size_t)b * H + min(max(ys + iy - 2, 0), H - 1)) * W * x_pitch + c0;
+        u32x4 cur[NC];
+#pragma unroll
+        for (int cx = 0; cx < NC; ++cx) cur[cx] = *reinterpret_cast<const u32x4*>(row + (size_t)min(max(xs - 2 + cx, 0), W - 1) * x_pitch);
+        fma_row(cur, iy, std::true_type{});
+      }
+    }
+    float sc[E], sh[E];
+#pragma unroll
+    for (int e = 0; e < E; e += 4) {
+      *reinterpret_cast<float4_t*>(&sc[e]) = *reinterpret_cast<const float4_t*>(scale + c0 + e);
+      *reinterpret_cast<float4_t*>(&sh[e]) = *reinterpret_cast<const float4_t*>(shift + c0 + e);
+    }
+    T* yrow = y + (((size_t)b * H + ys) * W) * y_pitch + c0;
+#pragma unroll
+    for (int o = 0; o < XS; ++o) {
+      if (xs + o >= W) break;
+      float v[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) v[e] = fmaxf(__builtin_fmaf(acc[o][e], sc[e], sh[e]), 0.f);
+      store16_stream(yrow + (size_t)(xs + o) * y_pitch, pack16<T>(v));
+    }
+  }
+}
+
+// Launch the persistent variant when it pays: 16-bit activations, the taps fit LDS, and every workgroup gets several rounds of
+// work to amortise staging the taps (25 x C x 4 bytes per workgroup out of the L2).  Returns false when the caller should use
+// the one-item-per-thread kernel.
+template <typename T>
+bool launch_dw_lds(const void* x, const float* w, const float* scale, const float* shift, void* y, int B, int C, int H, int W,
+                   int x_pitch, int y_pitch, hipStream_t s, int min_rounds, int* rc) {
+  const size_t smem = (size_t)25 * C * sizeof(float);
+  const size_t total = (size_t)B * H * ((W + 7) / 8) * (C / 8);
+  if (smem > 144 * 1024 || total >= (1u << 31) || (size_t)B * H * W * x_pitch * 2 >= (1ull << 32)) return false;
+  const int cus = num_cus();
+  const bool big = smem > 76 * 1024;                                // one 512-thread workgroup per CU instead of two of 256
+  const int nt = big ? 512 : 256, grid = (big ? cus : 2 * cus) & ~7;   // 8 XCD bands: a multiple of 8 workgroups
+  if (grid < 8) return false;
+  if (total < (size_t)(min_rounds > 1 ? min_rounds : 2) * grid * nt) return false;   // measured break-even (profiles/r02_dwconv_pmc.md)
+  const unsigned band = (unsigned)((total + 7) / 8);           // grid is a multiple of 8
+  static std::atomic<uint64_t> done_a{0}, done_b{0};
+  if (big) {
+    if ((*rc = ensure_dyn_smem(reinterpret_cast<const void*>(dwconv5x5_lds_kernel<T, 512>), (int)smem, done_a, "roma_dwconv5x5_bn_relu"))) return true;
+    hipLaunchKernelGGL((dwconv5x5_lds_kernel<T, 512>), dim3(grid), dim3(512), smem, s, (const T*)x, w, scale, shift, (T*)y, B, C, H, W,
+                       x_pitch, y_pitch, (unsigned)total, band);
+  } else {
+    if ((*rc = ensure_dyn_smem(reinterpret_cast<const void*>(dwconv5x5_lds_kernel<T, 256>), (int)smem, done_b, "roma_dwconv5x5_bn_relu"))) return true;
+    hipLaunchKernelGGL((dwconv5x5_lds_kernel<T, 256>), dim3(grid), dim3(256), smem, s, (const T*)x, w, scale, shift, (T*)y, B, C, H, W,
+                       x_pitch, y_pitch, (unsigned)total, band);
+  }
+  return true;
 }
 
 }  // namespace
@@ -143,6 +309,20 @@ extern "C" int roma_dwconv5x5_bn_relu(const void* x, const float* w, const float
   if (tile < 0) {
     const char* ev = getenv("ROMA_DW_TILE");
     tile = ev ? atoi(ev) : 81;
+  }
+  static int use_lds = -1;                                          // ROMA_DW_LDS=0: one-item-per-thread kernel everywhere; N >= 2: persistent from N rounds of work (A/B aids)
+  if (use_lds < 0) {
+    const char* ev = getenv("ROMA_DW_LDS");
+    use_lds = ev ? atoi(ev) : 1;
+  }
+  if (use_lds && dtype != ROMA_F32) {
+    int rc = 0;
+    const bool took = dtype == ROMA_F16 ? launch_dw_lds<half_t>(x, w, scale, shift, y, B, C, H, W, x_pitch, y_pitch, s, use_lds, &rc)
+                                        : launch_dw_lds<bf16_t>(x, w, scale, shift, y, B, C, H, W, x_pitch, y_pitch, s, use_lds, &rc);
+    if (took) {
+      if (rc) return rc;
+      ROMA_CHECK_LAUNCH();
+    }
   }
 #define ROMA_DW(T)                                                                                                    \
   switch (tile) {                                                                                                     \

@@ -507,6 +507,27 @@ def test_dwconv5x5_bn_relu(dtype, C, h, w):
     assert maxerr(out, ref) <= (2e-5 if dtype == torch.float32 else 4e-3)
 
 
+@pytest.mark.parametrize("dtype,C,h,w,pitch", [(torch.float16, 576, 150, 147, 576), (torch.float16, 1152, 108, 108, 1152),
+                                               (torch.bfloat16, 1408, 90, 93, 1408), (torch.float16, 144, 300, 301, 160)])
+def test_dwconv5x5_persistent_variant_shapes(dtype, C, h, w, pitch):
+    """Sizes at which roma_dwconv5x5_bn_relu takes the persistent kernel (taps in LDS, software-pipelined rows; >= 2 rounds of
+    work per workgroup): both workgroup sizes (taps <= / > 76 KB), widths that are not multiples of the 8-pixel strip, border
+    strips on all four sides, a channel pitch wider than C."""
+    import torch.nn.functional as F
+    B = 2
+    x = H.T(R.normal(f"dwp.x.{C}", (B, C, h, w))).to(dtype)
+    wt = H.T(R.normal(f"dwp.w.{C}", (C, 1, 5, 5), scale=0.2))
+    scale, shift = H.T(R.uniform("dwp.sc", (C,), 0.5, 1.5)), H.T(R.normal("dwp.sh", (C,), scale=0.1))
+    ref = F.relu(F.conv2d(x.float(), wt, None, 1, 2, groups=C) * scale[None, :, None, None] + shift[None, :, None, None])
+    ops = _ops()
+    xin = ops.nhwc_empty(B, C, h, w, dtype, DEV, pitch=pitch)
+    xin.copy_(x.to(DEV))
+    out = ops.nhwc_empty(B, C, h, w, dtype, DEV, pitch=pitch)
+    ops.dwconv5x5_bn_relu(xin, wt.reshape(C, 25).t().contiguous().to(DEV), scale.to(DEV), shift.to(DEV), out=out)
+    tol = 4e-3 if dtype == torch.float16 else 3e-2
+    assert maxerr(out, ref) <= tol * max(1.0, float(ref.abs().max()) / 4)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("C", [8, 24, 32])
 def test_pointwise_small(dtype, C):
