@@ -290,197 +290,10 @@ bool launch_dw_lds(const void* x, const float* w, const float* scale, const floa
 }
 
 
-// ---- column-marching variant, 16-bit activations (round 2, second step) ---------------------------------------------------------
-// The two kernels above convert every input row five times (once per output row that uses it) and load it five times: 480 of the
-// 1 450 loop instructions per item are fp16 -> fp32 conversions, and the L1 moves 7.5 packets per output packet.  Here a thread owns
-// 4 channels x a 4-pixel strip and MARCHES down a segment of rows with the last five input rows (8 columns x 4 channels, fp32) in
-// a 160-register ring: every input element is loaded and converted once per strip (twice in all: the strips overlap by half in x),
-// the 25 taps come from LDS as one ds_read_b128 each, and an output row costs 200 v_pk_fma_f32 + 32 conversions + the BN/ReLU/pack
-// epilogue.  The ring rotates by renaming: the row loop is unrolled five-fold with compile-time slots.  The segment length is chosen
-// on the host so that all threads of the launch are resident at once (no tail); segments re-load 4 halo rows each.
-__device__ __forceinline__ void store8_stream(void* p, uint32_t a, uint32_t b) {
-  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-  const u32x2 v{a, b};
-  asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 0" : : "v"(p), "v"(v) : "memory");
-}
-
-template <typename T> __device__ __forceinline__ void unpack4(uint32_t lo, uint32_t hi, float* f);
-template <> __device__ __forceinline__ void unpack4<half_t>(uint32_t lo, uint32_t hi, float* f) {
-  const half2_t a = __builtin_bit_cast(half2_t, lo), b = __builtin_bit_cast(half2_t, hi);
-  f[0] = (float)a[0]; f[1] = (float)a[1]; f[2] = (float)b[0]; f[3] = (float)b[1];
-}
-template <> __device__ __forceinline__ void unpack4<bf16_t>(uint32_t lo, uint32_t hi, float* f) {
-  f[0] = __uint_as_float(lo << 16); f[1] = __uint_as_float(lo & 0xffff0000u);
-  f[2] = __uint_as_float(hi << 16); f[3] = __uint_as_float(hi & 0xffff0000u);
-}
-template <typename T> __device__ __forceinline__ uint32_t pack2(float a, float b);
-template <> __device__ __forceinline__ uint32_t pack2<half_t>(float a, float b) { return __builtin_bit_cast(uint32_t, half2_t{(half_t)a, (half_t)b}); }
-template <> __device__ __forceinline__ uint32_t pack2<bf16_t>(float a, float b) { return __builtin_bit_cast(uint32_t, bf162_t{(bf16_t)a, (bf16_t)b}); }
-
-template <typename T, int NT, int PF>
-__global__ __launch_bounds__(NT) void dwconv5x5_march_kernel(const T* __restrict__ x, const float* __restrict__ w,
-                                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
-                                                                                 T* __restrict__ y, int B, int C, int H, int W, int x_pitch,
-                                                                                 int y_pitch, int L, int nseg, unsigned total) {
-  static_assert(sizeof(T) == 2, "16-bit activations");
-  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-  constexpr int XS = 4, NC = XS + 4, E = 4;
-  extern __shared__ __attribute__((aligned(16))) float s_w[];     // [25][C]
-  const int tid = threadIdx.x;
-  {
-    constexpr int SB = 8;
-    const int n4 = 25 * C / 4;
-    for (int e0 = tid; e0 < n4; e0 += NT * SB) {
-      float4_t t[SB];
-#pragma unroll
-      for (int j = 0; j < SB; ++j) t[j] = reinterpret_cast<const float4_t*>(w)[min(e0 + j * NT, n4 - 1)];
-#pragma unroll
-      for (int j = 0; j < SB; ++j)
-        if (e0 + j * NT < n4) reinterpret_cast<float4_t*>(s_w)[e0 + j * NT] = t[j];
-    }
-  }
-  __syncthreads();
-  const unsigned i = (unsigned)xcd_remap(blockIdx.x, gridDim.x) * NT + tid;
-  if (i >= total) return;                                          // no barrier below
-  const unsigned CG = (unsigned)C / E, WS = (unsigned)(W + XS - 1) / XS;
-  const unsigned cg = i % CG;
-  unsigned r = i / CG;
-  const int xs = (int)(r % WS) * XS;
-  r /= WS;
-  const int seg = (int)(r % (unsigned)nseg), b = (int)(r / (unsigned)nseg);
-  const int c0 = (int)cg * E;
-  const int y0 = seg * L, yend = min(y0 + L, H);                   // output rows of this thread
-  const bool edge = xs < 2 || xs + XS + 2 > W;                     // a column of the 8 falls outside the map
-  const bool wave_edge = __any(edge);
-  const float* wl = s_w + c0;
-
-  typedef float f2 __attribute__((ext_vector_type(2)));
-  f2 buf[5][NC][2];                                                // the last five input rows, fp32 (compile-time slots only)
-  u32x2 raw[5][NC];                                                // rows in flight: PF of the 5 slots (slot = row % 5, like buf)
-  auto load_row = [&](auto slot_c, int yi) {                       // request input row yi (clamped; zeroed at conversion if outside)
-    constexpr int S = decltype(slot_c)::value;
-    const int yc = min(max(yi, 0), H - 1);
-    if (!wave_edge) {
-      const unsigned voff = (unsigned)((((size_t)b * H + yc) * W + xs - 2) * x_pitch + c0) * 2u;
-#pragma unroll
-      for (int cx = 0; cx < NC; ++cx)
-        raw[S][cx] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const char*>(x) + (size_t)cx * x_pitch * 2 + voff);
-    } else {
-#pragma unroll
-      for (int cx = 0; cx < NC; ++cx)
-        raw[S][cx] = *reinterpret_cast<const u32x2*>(x + (((size_t)b * H + yc) * W + min(max(xs - 2 + cx, 0), W - 1)) * x_pitch + c0);
-    }
-  };
-  // one step of the march: input row rr lands in slot P, the row after it is requested, and (kCompute) output row rr - 4 leaves
-  auto phase = [&](auto pc, auto compute_c, int rr) {
-    constexpr int P = decltype(pc)::value;
-    const int yi = y0 - 2 + rr;
-    const bool yin = yi >= 0 && yi < H;
-    const bool mask_any = wave_edge || __any(!yin);
-#pragma unroll
-    for (int cx = 0; cx < NC; ++cx) {
-      float f[E];
-      unpack4<T>(raw[P][cx][0], raw[P][cx][1], f);
-      buf[P][cx][0] = f2{f[0], f[1]};
-      buf[P][cx][1] = f2{f[2], f[3]};
-    }
-    if (mask_any) {                                                // ONE wave-uniform branch per row (a per-column test shreds the schedule)
-#pragma unroll
-      for (int cx = 0; cx < NC; ++cx) {
-        const int xi = xs - 2 + cx;
-        const float m = (yin && xi >= 0 && xi < W) ? 1.f : 0.f;
-        buf[P][cx][0] *= m;
-        buf[P][cx][1] *= m;
-      }
-    }
-    load_row(std::integral_constant<int, (P + PF) % 5>{}, yi + PF);   // PF rows ahead: in flight across PF rows of multiply-adds
-    if constexpr (decltype(compute_c)::value) {
-      f2 acc[XS][2];
-#pragma unroll
-      for (int o = 0; o < XS; ++o) acc[o][0] = acc[o][1] = f2{0.f, 0.f};
-      float4_t wt[2][5];                                            // tap rows: the next one is read while this one is multiplied
-#pragma unroll
-      for (int dx = 0; dx < 5; ++dx) wt[0][dx] = *reinterpret_cast<const float4_t*>(wl + (size_t)dx * C);
-#pragma unroll
-      for (int dy = 0; dy < 5; ++dy) {
-        if (dy < 4) {
-#pragma unroll
-          for (int dx = 0; dx < 5; ++dx) wt[(dy + 1) & 1][dx] = *reinterpret_cast<const float4_t*>(wl + (size_t)((dy + 1) * 5 + dx) * C);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int dx = 0; dx < 5; ++dx) {
-          const float4_t wv = wt[dy & 1][dx];
-          const f2 w0 = __builtin_shufflevector(wv, wv, 0, 1), w1 = __builtin_shufflevector(wv, wv, 2, 3);
-#pragma unroll
-          for (int o = 0; o < XS; ++o) {
-            acc[o][0] = __builtin_elementwise_fma(w0, buf[(P + 1 + dy) % 5][o + dx][0], acc[o][0]);
-            acc[o][1] = __builtin_elementwise_fma(w1, buf[(P + 1 + dy) % 5][o + dx][1], acc[o][1]);
-          }
-        }
-        // pin the tap row here: without it LLVM sinks all 200 multiply-adds into the `yo < yend` block below, behind all 25 tap reads
-        asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]),
-                     "+v"(acc[3][0]), "+v"(acc[3][1]));
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      const int yo = y0 + rr - 4;
-      if (yo < yend) {
-        T* yrow = y + (((size_t)b * H + yo) * W) * y_pitch + c0;
-        // BN constants re-read per row (L1-resident): 8 registers that the ring needs more
-        const float4_t sc = *reinterpret_cast<const float4_t*>(scale + c0), sh = *reinterpret_cast<const float4_t*>(shift + c0);
-        const f2 sc0 = __builtin_shufflevector(sc, sc, 0, 1), sc1 = __builtin_shufflevector(sc, sc, 2, 3);
-        const f2 sh0 = __builtin_shufflevector(sh, sh, 0, 1), sh1 = __builtin_shufflevector(sh, sh, 2, 3);
-#pragma unroll
-        for (int o = 0; o < XS; ++o) {
-          if (xs + o >= W) break;
-          const f2 v0 = __builtin_elementwise_fma(acc[o][0], sc0, sh0), v1 = __builtin_elementwise_fma(acc[o][1], sc1, sh1);
-          store8_stream(yrow + (size_t)(xs + o) * y_pitch, pack2<T>(fmaxf(v0[0], 0.f), fmaxf(v0[1], 0.f)),
-                        pack2<T>(fmaxf(v1[0], 0.f), fmaxf(v1[1], 0.f)));
-        }
-      }
-    }
-  };
-  using std::integral_constant;
-  load_row(integral_constant<int, 0>{}, y0 - 2);
-  if constexpr (PF > 1) load_row(integral_constant<int, 1>{}, y0 - 1);
-  if constexpr (PF > 2) load_row(integral_constant<int, 2>{}, y0);
-  if constexpr (PF > 3) load_row(integral_constant<int, 3>{}, y0 + 1);
-  phase(integral_constant<int, 0>{}, std::false_type{}, 0);        // warm-up: four halo rows
-  phase(integral_constant<int, 1>{}, std::false_type{}, 1);
-  phase(integral_constant<int, 2>{}, std::false_type{}, 2);
-  phase(integral_constant<int, 3>{}, std::false_type{}, 3);
-#pragma unroll 1
-  for (int rr = 4; rr < L + 4; rr += 5) {                          // L is a multiple of 5 (host): five output rows per trip, the ring
-    phase(integral_constant<int, 4>{}, std::true_type{}, rr);      // rotates by renaming
-    phase(integral_constant<int, 0>{}, std::true_type{}, rr + 1);
-    phase(integral_constant<int, 1>{}, std::true_type{}, rr + 2);
-    phase(integral_constant<int, 2>{}, std::true_type{}, rr + 3);
-    phase(integral_constant<int, 3>{}, std::true_type{}, rr + 4);
-  }
-}
-
-// Host side of the marching kernel: segment length such that one launch fills the chip once.  false = not applicable.
-template <typename T>
-bool launch_dw_march(const void* x, const float* w, const float* scale, const float* shift, void* y, int B, int C, int H, int W,
-                     int x_pitch, int y_pitch, hipStream_t s, int* rc) {
-  const size_t smem = (size_t)25 * C * sizeof(float);
-  if (smem > 144 * 1024 || (size_t)B * H * W * x_pitch * 2 >= (1ull << 32)) return false;
-  const size_t cols = (size_t)B * ((W + 3) / 4) * (C / 4);
-  constexpr int nt = 256, PF = 3;
-  const size_t capacity = (size_t)num_cus() * nt;                   // one workgroup per CU, one wave per SIMD (the ring needs > 256 registers)
-  int nseg = (int)(capacity / cols);
-  nseg = nseg < 1 ? 1 : (nseg > H / 8 ? (H / 8 > 0 ? H / 8 : 1) : nseg);
-  const int L = ((H + nseg - 1) / nseg + 4) / 5 * 5;                // a multiple of 5: the row ring rotates once per loop trip
-  nseg = (H + L - 1) / L;
-  const size_t total = cols * nseg;
-  if (total >= (1u << 31)) return false;
-  const int grid = (int)((total + nt - 1) / nt);
-  static std::atomic<uint64_t> done{0};
-  if ((*rc = ensure_dyn_smem(reinterpret_cast<const void*>(dwconv5x5_march_kernel<T, nt, PF>), (int)smem, done, "roma_dwconv5x5_bn_relu"))) return true;
-  hipLaunchKernelGGL((dwconv5x5_march_kernel<T, nt, PF>), dim3(grid), dim3(nt), smem, s, (const T*)x, w, scale, shift, (T*)y, B, C, H, W,
-                     x_pitch, y_pitch, L, nseg, (unsigned)total);
-  return true;
-}
+// A third design was built and measured in round 2 (commit 2e370cf, "column-marching"): 4 channels x a 4-pixel strip per thread
+// marching down a row segment with the last five input rows as fp32 in a 160-register ring, so that every input is converted
+// once instead of five times (19 % fewer VALU instructions, FETCH_SIZE 1.23 x the input).  Parity-green, but the ring leaves one
+// wave per SIMD and every LDS / HBM wait is exposed: 86.7 us against this file's 67.8 us at C = 576, 216 x 216.  Removed again.
 
 }  // namespace
 }  // namespace roma
@@ -507,20 +320,6 @@ extern "C" int roma_dwconv5x5_bn_relu(const void* x, const float* w, const float
   if (use_lds < 0) {
     const char* ev = getenv("ROMA_DW_LDS");
     use_lds = ev ? atoi(ev) : 1;
-  }
-  static int use_march = -1;                                        // ROMA_DW_MARCH=1: column-marching kernel for 16-bit activations
-  if (use_march < 0) {
-    const char* ev = getenv("ROMA_DW_MARCH");
-    use_march = ev ? atoi(ev) : 0;
-  }
-  if (use_march && dtype != ROMA_F32) {
-    int rc = 0;
-    const bool took = dtype == ROMA_F16 ? launch_dw_march<half_t>(x, w, scale, shift, y, B, C, H, W, x_pitch, y_pitch, s, &rc)
-                                        : launch_dw_march<bf16_t>(x, w, scale, shift, y, B, C, H, W, x_pitch, y_pitch, s, &rc);
-    if (took) {
-      if (rc) return rc;
-      ROMA_CHECK_LAUNCH();
-    }
   }
   if (use_lds && dtype != ROMA_F32) {
     int rc = 0;
