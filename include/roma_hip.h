@@ -102,6 +102,27 @@ int roma_cos_kernel(const void* x, const void* y, float* K, int B, int N, int M,
 int roma_chol_diag_block(float* A, int lda, long strideA, float* W, int ldw, long strideW, int nb, int B, int* info,
                          int info_base, void* stream);
 
+/* One fused forward step of the same blocked solve (matcher.py:259-263) on the augmented matrix A = [K | F] (B matrices, n rows,
+ * ncols = n + m columns, row-major, lda, strideA): for the block rows [j, j+nb) whose diagonal block has already been factored
+ * (W = the inverse of its Cholesky factor, from roma_chol_diag_block or from the previous call), with e = j + nb:
+ *   R (nb x (ncols - e), ldr, strideR)  <-  W A[j:j+nb, e:]            (= [L[e:, j:j+nb]^T | Y[j:j+nb]]: needed by the back substitution)
+ *   A[e:n, e:ncols]                     -=  R[:, :n-e]^T R             (only the 64 x 64 tiles on or right of the diagonal are updated)
+ *   the next diagonal block A[e:e+nbn, e:e+nbn], nbn = min(64, n - e), is replaced by its Cholesky factor (lower triangle) and
+ *   Wn (nbn x nbn, ldwn, strideWn) receives its inverse; info as in roma_chol_diag_block with info_base for THAT block.
+ * Wn may be NULL (no factorisation; the last block).  One launch instead of the three per block of the GEMM formulation. */
+int roma_chol_step(float* A, int lda, long strideA, int n, int ncols, int j, int nb, const float* W, int ldw, long strideW, float* R,
+                   int ldr, long strideR, float* Wn, int ldwn, long strideWn, int* info, int info_base, int B, void* stream);
+
+/* One fused step of the back substitution L^T X = Y of the same solve.  R holds ALL panels written by roma_chol_step: panel i of
+ * matrix b starts at R + b*strideRb + i*strideRs (nb rows, leading dimension ldr) and is [L[e_i:, block i]^T | T_i] with
+ * e_i = min((i+1) nb, n): n - e_i columns of the transposed Cholesky panel, then m columns that start as Y_i.  For block row s
+ * (call with s = S-1 down to 0; W = the inverse factor of diagonal block s):
+ *   X[s nb : s nb + w_s, :]  <-  W^T T_s                         (X: n x m, ldx, strideX)
+ *   T_i  -=  L[block s, block i]^T X_s     for every i < s        (in place, in R)
+ * nb = 64 (a single-block solve may use any nb <= 64).  One launch instead of the two GEMMs per block of the GEMM formulation. */
+int roma_chol_back_step(const float* W, int ldw, long strideW, float* R, long strideRb, long strideRs, int ldr, float* X, int ldx,
+                        long strideX, int n, int m, int nb, int s, int B, void* stream);
+
 /* match() post-processing — matcher.py:656-662, 684-718: certainty attenuation by the coarse scale-16 certainty,
  * sigmoid, zeroing where |flow|>1, clamp, symmetric concat.
  *   flow (2P,2,H,W), cert (2P,1,H,W) fp32 planar: first P = A->B, last P = B->A (forward_symmetric, matcher.py:516-528)

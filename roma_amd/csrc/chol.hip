@@ -29,25 +29,12 @@ __device__ __forceinline__ float lane_bcast(float v, int src_lane) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src_lane));
 }
 
-__global__ __launch_bounds__(256) void chol_diag_kernel(float* __restrict__ A, int lda, long strideA, float* __restrict__ W, int ldw,
-                                                        long strideW, int nb, int* __restrict__ info, int info_base) {
-  __shared__ float Ls[NBMAX * LDS_LD];                           // the block, then its factor L (lower; strict upper = garbage)
-  __shared__ float Ws[NBMAX * LDS_LD];                           // L^-1
-  __shared__ float Ts[32 * 33];                                  // product scratch of the inverse
-  __shared__ float s_inv[NBMAX];                                 // 1 / L[i][i]
-  __shared__ int s_bad;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
-  float* Ab = A + (size_t)b * strideA;
-  float* Wb = W + (size_t)b * strideW;
-  if (tid == 0) s_bad = 0;
-  // load, identity-padded beyond nb (so partial blocks factor like full ones)
-  for (int e = tid; e < NBMAX * NBMAX; e += 256) {
-    const int r = e >> 6, c = e & 63;
-    Ls[r * LDS_LD + c] = (r < nb && c < nb) ? Ab[(size_t)r * lda + c] : (r == c ? 1.f : 0.f);
-    Ws[r * LDS_LD + c] = 0.f;
-  }
-  __syncthreads();
-
+// Factor the NBMAX x NBMAX block in Ls (row stride LDS_LD, identity-padded beyond the caller's nb) in place and leave L^-1 in Ws
+// (zero-initialised by the caller).  Whole 256-thread workgroup; s_bad receives the first failing pivot + 1 (0: none).
+__device__ __forceinline__ void chol_factor_lds(float* __restrict__ Ls, float* __restrict__ Ws, float* __restrict__ Ts,
+                                                float* __restrict__ s_inv, int* __restrict__ s_bad_p, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  int& s_bad = *s_bad_p;
 #pragma unroll
   for (int p = 0; p < NBMAX / PB; ++p) {
     const int o = p * PB;                                        // first row / column of the panel
@@ -151,6 +138,29 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(float* __restrict__ A, i
   offdiag(3 * PB, 2 * PB, std::integral_constant<int, PB>{});   //      inside the lower-right 32 x 32 half
   offdiag(2 * PB, 0, std::integral_constant<int, 2 * PB>{});    // (4c) the 32 x 32 block below the diagonal
 
+}
+
+__global__ __launch_bounds__(256) void chol_diag_kernel(float* __restrict__ A, int lda, long strideA, float* __restrict__ W, int ldw,
+                                                        long strideW, int nb, int* __restrict__ info, int info_base) {
+  __shared__ float Ls[NBMAX * LDS_LD];                           // the block, then its factor L (lower; strict upper = garbage)
+  __shared__ float Ws[NBMAX * LDS_LD];                           // L^-1
+  __shared__ float Ts[32 * 33];                                  // product scratch of the inverse
+  __shared__ float s_inv[NBMAX];                                 // 1 / L[i][i]
+  __shared__ int s_bad;
+  const int tid = threadIdx.x, b = blockIdx.x;
+  float* Ab = A + (size_t)b * strideA;
+  float* Wb = W + (size_t)b * strideW;
+  if (tid == 0) s_bad = 0;
+  // load, identity-padded beyond nb (so partial blocks factor like full ones)
+  for (int e = tid; e < NBMAX * NBMAX; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    Ls[r * LDS_LD + c] = (r < nb && c < nb) ? Ab[(size_t)r * lda + c] : (r == c ? 1.f : 0.f);
+    Ws[r * LDS_LD + c] = 0.f;
+  }
+  __syncthreads();
+
+  chol_factor_lds(Ls, Ws, Ts, s_inv, &s_bad, tid);
+
   // store: L over the lower triangle of the block, W in full (zero above its diagonal)
   for (int e = tid; e < NBMAX * NBMAX; e += 256) {
     const int r = e >> 6, c = e & 63;
@@ -160,6 +170,254 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(float* __restrict__ A, i
     }
   }
   if (tid == 0 && s_bad != 0 && s_bad <= nb && info[b] == 0) info[b] = info_base + s_bad;   // the FIRST failing pivot of the whole solve
+}
+
+
+typedef float f2_t __attribute__((ext_vector_type(2)));
+
+// acc (4 x 4 outputs as 4 x 2 packed pairs) += sum_k a[k][ra..ra+3] (x) b[k][cb..cb+3] over the 64 rows of two LDS tiles
+// (row stride TLD): v_pk_fma_f32, two outputs per instruction.
+__device__ __forceinline__ void tile_product(const float* __restrict__ sa, const float* __restrict__ sb, int ra, int cb, f2_t (&acc)[4][2]) {
+#pragma unroll 8
+  for (int k = 0; k < 64; ++k) {
+    const float4_t a4 = *reinterpret_cast<const float4_t*>(sa + k * 68 + ra);
+    const float4_t b4 = *reinterpret_cast<const float4_t*>(sb + k * 68 + cb);
+    const f2_t b01 = __builtin_shufflevector(b4, b4, 0, 1), b23 = __builtin_shufflevector(b4, b4, 2, 3);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const f2_t ar{a4[r], a4[r]};
+      acc[r][0] = __builtin_elementwise_fma(ar, b01, acc[r][0]);
+      acc[r][1] = __builtin_elementwise_fma(ar, b23, acc[r][1]);
+    }
+  }
+}
+
+// ---- one fused forward step of the blocked solve (round 2) ----------------------------------------------------------------------
+// ops.spd_solve ran, per 64-row block s of the augmented matrix A = [K | F]: this file's diagonal-block kernel, a GEMM
+// r = W_s A[j:e, e:] and a GEMM A[e:, e:] -= r[:, :n-e]^T r — 75 dependent launches of 5-25 us kernels on the critical path of the
+// coarse pass.  This kernel is one launch per block: every 64 x 64 tile (I, J >= I) of the trailing matrix recomputes the two row
+// panels it needs, r_I = W_s A[j:e, I] and r_J (64^3 products out of LDS; redundant across tiles, but no tile waits for another),
+// applies A[I, J] -= r_I^T r_J, and the workgroup that owns the NEXT diagonal tile factors it in place (chol_factor_lds) and emits
+// W_{s+1}.  Only tiles J >= I are kept up to date: the next step reads the row block A[e:e+64, e+64:] and nothing below the diagonal.
+// "R tiles" (one per column tile) write the panel r itself, which the backward substitution needs.
+struct StepParams {
+  float* A; int lda; long strideA; int n, ncols, j, nb;
+  const float* W; int ldw; long strideW;
+  float* R; int ldr; long strideR;
+  float* Wn; int ldwn; long strideWn;
+  int* info; int info_base;
+  int ntr, ntc;                                                   // row / column tiles of the trailing region
+};
+
+constexpr int TS = 64, TLD = 68;                                  // tile size; LDS row stride (16-byte aligned rows, 4-bank skew)
+
+__global__ __launch_bounds__(256) void chol_step_kernel(StepParams p) {
+  __shared__ __attribute__((aligned(16))) float smem[3 * TS * TLD + NBMAX + 4];
+  float* sWT = smem;                                              // W^T
+  float* sI = smem + TS * TLD;                                    // A[j:e, I-range], then r_I
+  float* sJ = smem + 2 * TS * TLD;                                // A[j:e, J-range], then r_J
+  const int tid = threadIdx.x, b = blockIdx.y;
+  const int e = p.j + p.nb;
+  // tile id -> kind: the first ntc ids are R tiles (J = id); then the update tiles row by row, J = I .. ntc-1
+  int id = blockIdx.x, I = -1, J = id;
+  if (id >= p.ntc) {
+    id -= p.ntc;
+    I = 0;
+    while (id >= p.ntc - I) { id -= p.ntc - I; ++I; }
+    J = I + id;
+  }
+  float* Ab = p.A + (size_t)b * p.strideA;
+  const float* Wb = p.W + (size_t)b * p.strideW;
+  for (int idx = tid; idx < TS * TS; idx += 256) {                 // W^T, zero-padded beyond nb
+    const int k = idx >> 6, q = idx & 63;
+    sWT[q * TLD + k] = (k < p.nb && q < p.nb) ? Wb[(size_t)k * p.ldw + q] : 0.f;
+  }
+  const int J0 = e + J * TS, I0 = e + (I < 0 ? 0 : I) * TS;
+  for (int idx = tid; idx < TS * TS; idx += 256) {                 // the row block's columns of this tile (coalesced along c)
+    const int q = idx >> 6, c = idx & 63;
+    sJ[q * TLD + c] = (q < p.nb && J0 + c < p.ncols) ? Ab[(size_t)(p.j + q) * p.lda + J0 + c] : 0.f;
+    if (I >= 0 && I != J) sI[q * TLD + c] = (q < p.nb && I0 + c < p.n) ? Ab[(size_t)(p.j + q) * p.lda + I0 + c] : 0.f;
+  }
+  __syncthreads();
+  const int t4r = (tid >> 4) * 4, t4c = (tid & 15) * 4;           // 4 x 4 outputs per thread
+  auto panel = [&](const float* sX, float (&out)[4][4]) {          // out = (W A_X)[t4r.., t4c..]
+    f2_t acc[4][2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r][0] = acc[r][1] = f2_t{0.f, 0.f};
+    tile_product(sWT, sX, t4r, t4c, acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { out[r][0] = acc[r][0][0]; out[r][1] = acc[r][0][1]; out[r][2] = acc[r][1][0]; out[r][3] = acc[r][1][1]; }
+  };
+  float aold[4][4];                                                // this tile of A: requested now, needed after the three products
+  if (I >= 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int row = I0 + t4r + r, col = J0 + t4c + c;
+        aold[r][c] = (row < p.n && col < p.ncols) ? Ab[(size_t)row * p.lda + col] : 0.f;
+      }
+  }
+  float rj[4][4], ri[4][4];
+  panel(sJ, rj);
+  if (I >= 0 && I != J) panel(sI, ri);
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    *reinterpret_cast<float4_t*>(sJ + (t4r + r) * TLD + t4c) = float4_t{rj[r][0], rj[r][1], rj[r][2], rj[r][3]};
+    if (I >= 0 && I != J) *reinterpret_cast<float4_t*>(sI + (t4r + r) * TLD + t4c) = float4_t{ri[r][0], ri[r][1], ri[r][2], ri[r][3]};
+  }
+  __syncthreads();
+  if (I < 0) {                                                     // R tile: store the panel
+    float* Rb = p.R + (size_t)b * p.strideR;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = t4r + r;
+      if (k >= p.nb) continue;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (J0 + t4c + c < p.ncols) Rb[(size_t)k * p.ldr + (J0 - e) + t4c + c] = rj[r][c];
+    }
+    return;
+  }
+  const float* sL = (I == J) ? sJ : sI;                            // r_I
+  f2_t acc2[4][2];                                                 // (r_I^T r_J)[t4r.., t4c..]; rows k >= nb of both panels are zero
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc2[r][0] = acc2[r][1] = f2_t{0.f, 0.f};
+  tile_product(sL, sJ, t4r, t4c, acc2);
+  float acc[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { acc[r][0] = acc2[r][0][0]; acc[r][1] = acc2[r][0][1]; acc[r][2] = acc2[r][1][0]; acc[r][3] = acc2[r][1][1]; }
+  const bool next_diag = (I == 0 && J == 0 && p.Wn != nullptr);
+  float outv[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = I0 + t4r + r;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int col = J0 + t4c + c;
+      const bool in = row < p.n && col < p.ncols;
+      float v = in ? aold[r][c] - acc[r][c] : 0.f;
+      outv[r][c] = v;
+      if (in) Ab[(size_t)row * p.lda + col] = v;
+    }
+  }
+  if (!next_diag) return;
+  // ---- the next diagonal block: factor it here, in the workgroup that just produced it ----
+  __syncthreads();                                                 // the panels in LDS are dead from here
+  float* Ls = smem;                                                // NBMAX x LDS_LD
+  float* Ws = smem + NBMAX * LDS_LD;
+  float* Ts = smem + 2 * NBMAX * LDS_LD;                           // 32 x 33
+  float* s_inv = smem + 3 * TS * TLD;
+  int* s_bad = reinterpret_cast<int*>(smem + 3 * TS * TLD + NBMAX);
+  static_assert(2 * NBMAX * LDS_LD + 32 * 33 <= 3 * TS * TLD, "factor scratch must fit the panel buffers");
+  const int nbn = min(NBMAX, p.n - e);
+  if (tid == 0) *s_bad = 0;
+  for (int idx = tid; idx < NBMAX * NBMAX; idx += 256) Ws[(idx >> 6) * LDS_LD + (idx & 63)] = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int rr = t4r + r, cc = t4c + c;
+      Ls[rr * LDS_LD + cc] = (rr < nbn && cc < nbn) ? outv[r][c] : (rr == cc ? 1.f : 0.f);
+    }
+  __syncthreads();
+  chol_factor_lds(Ls, Ws, Ts, s_inv, s_bad, tid);
+  float* Wnb = p.Wn + (size_t)b * p.strideWn;
+  for (int idx = tid; idx < NBMAX * NBMAX; idx += 256) {
+    const int r = idx >> 6, c = idx & 63;
+    if (r < nbn && c < nbn) {
+      if (c <= r) Ab[(size_t)(e + r) * p.lda + e + c] = Ls[r * LDS_LD + c];
+      Wnb[(size_t)r * p.ldwn + c] = Ws[r * LDS_LD + c];
+    }
+  }
+  if (tid == 0 && *s_bad != 0 && *s_bad <= nbn && p.info[b] == 0) p.info[b] = p.info_base + *s_bad;
+}
+
+
+// ---- one fused step of the back substitution L^T X = Y (round 2) ---------------------------------------------------------------------
+// Block row s (from the last to the first): X_s = W_s^T T_s, then every block row i < s takes T_i -= L[s, i]^T X_s, where T_i starts as
+// the Y part of panel i and L[s, i]^T is the (rows of block i) x (columns of block s) piece of panel i (roma_chol_step's R).  One
+// launch per block row instead of two GEMMs: every (i, 64-column tile c) workgroup recomputes the X_s tile it needs (one 64^3
+// product; no workgroup waits for another) and applies its update; "X tiles" (one per c) store X_s.
+struct BackParams {
+  const float* W; int ldw; long strideW;                          // W_s
+  float* R; long strideRb, strideRs; int ldr;                     // all panels: panel i of matrix b at R + b*strideRb + i*strideRs
+  float* X; int ldx; long strideX;
+  int n, m, nb, s, ctiles;
+};
+
+__global__ __launch_bounds__(256) void chol_back_kernel(BackParams p) {
+  __shared__ __attribute__((aligned(16))) float smem[3 * TS * TLD];
+  float* sW = smem;                                               // W_s, then L[s, i] ( = (panel piece)^T )
+  float* sT = smem + TS * TLD;                                    // T_s tile
+  float* sX = smem + 2 * TS * TLD;                                // X_s tile
+  const int tid = threadIdx.x, b = blockIdx.y;
+  int id = blockIdx.x, i = -1, c;
+  if (id < p.ctiles) c = id; else { id -= p.ctiles; i = id / p.ctiles; c = id - i * p.ctiles; }
+  const int js = p.s * p.nb, es = min(js + p.nb, p.n), ws = es - js;
+  const float* Wb = p.W + (size_t)b * p.strideW;
+  float* Rb = p.R + (size_t)b * p.strideRb;
+  const float* Ts = Rb + (size_t)p.s * p.strideRs + (p.n - es);   // Y / T part of panel s
+  const int c0 = c * TS;
+  const int t4r = (tid >> 4) * 4, t4c = (tid & 15) * 4;
+  for (int idx = tid; idx < TS * TS; idx += 256) {
+    const int k = idx >> 6, q = idx & 63;
+    sW[k * TLD + q] = (k < ws && q < ws) ? Wb[(size_t)k * p.ldw + q] : 0.f;
+    sT[k * TLD + q] = (k < ws && c0 + q < p.m) ? Ts[(size_t)k * p.ldr + c0 + q] : 0.f;
+  }
+  __syncthreads();
+  // this workgroup's T_i tile and its piece of panel i: requested now, consumed after the first product
+  const int ei = (i + 1) * p.nb;                                   // i < s: block i is a full one
+  float* Pi = Rb + (size_t)(i < 0 ? 0 : i) * p.strideRs;          // panel i: [L[e_i:, block i]^T | T_i]
+  float* Ti = Pi + (p.n - ei);
+  float told[4][4], lpiece[16];
+  if (i >= 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc)
+        told[r][cc] = (t4r + r < p.nb && c0 + t4c + cc < p.m) ? Ti[(size_t)(t4r + r) * p.ldr + c0 + t4c + cc] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int idx = tid + 256 * u, r = idx >> 6, q = idx & 63;
+      lpiece[u] = (r < p.nb && q < ws) ? Pi[(size_t)r * p.ldr + (js - ei) + q] : 0.f;
+    }
+  }
+  f2_t x2[4][2];                                                   // X_s[q][col] = sum_k W_s[k][q] T_s[k][col]
+#pragma unroll
+  for (int r = 0; r < 4; ++r) x2[r][0] = x2[r][1] = f2_t{0.f, 0.f};
+  tile_product(sW, sT, t4r, t4c, x2);
+  float xs[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { xs[r][0] = x2[r][0][0]; xs[r][1] = x2[r][0][1]; xs[r][2] = x2[r][1][0]; xs[r][3] = x2[r][1][1]; }
+  if (i < 0) {                                                     // X tile: store
+    float* Xb = p.X + (size_t)b * p.strideX;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc)
+        if (t4r + r < ws && c0 + t4c + cc < p.m) Xb[(size_t)(js + t4r + r) * p.ldx + c0 + t4c + cc] = xs[r][cc];
+    return;
+  }
+  __syncthreads();                                                 // every thread is done with sW
+#pragma unroll
+  for (int r = 0; r < 4; ++r) *reinterpret_cast<float4_t*>(sX + (t4r + r) * TLD + t4c) = float4_t{xs[r][0], xs[r][1], xs[r][2], xs[r][3]};
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {                                   // sW[q][r] = L[s, i][q][r] = panel_i[r][(js - e_i) + q]
+    const int idx = tid + 256 * u, r = idx >> 6, q = idx & 63;
+    sW[q * TLD + r] = lpiece[u];
+  }
+  __syncthreads();
+  f2_t acc2[4][2];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc2[r][0] = acc2[r][1] = f2_t{0.f, 0.f};
+  tile_product(sW, sX, t4r, t4c, acc2);
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc)
+      if (t4r + r < p.nb && c0 + t4c + cc < p.m) Ti[(size_t)(t4r + r) * p.ldr + c0 + t4c + cc] = told[r][cc] - acc2[r][cc >> 1][cc & 1];
 }
 
 }  // namespace
@@ -172,5 +430,34 @@ extern "C" int roma_chol_diag_block(float* A, int lda, long strideA, float* W, i
   ROMA_REQUIRE(A && W && info, ROMA_E_ARG, "roma_chol_diag_block: null pointer");
   ROMA_REQUIRE(nb >= 1 && nb <= NBMAX && B >= 1 && lda >= nb && ldw >= nb, ROMA_E_SHAPE, "roma_chol_diag_block: bad shape nb=%d B=%d", nb, B);
   hipLaunchKernelGGL(chol_diag_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), A, lda, strideA, W, ldw, strideW, nb, info, info_base);
+  ROMA_CHECK_LAUNCH();
+}
+
+extern "C" int roma_chol_step(float* A, int lda, long strideA, int n, int ncols, int j, int nb, const float* W, int ldw, long strideW,
+                              float* R, int ldr, long strideR, float* Wn, int ldwn, long strideWn, int* info, int info_base, int B,
+                              void* stream) {
+  ROMA_REQUIRE(A && W && R && info, ROMA_E_ARG, "roma_chol_step: null pointer");
+  ROMA_REQUIRE(nb >= 1 && nb <= NBMAX && B >= 1 && n >= 1 && ncols >= n && j >= 0 && j + nb <= n && lda >= ncols && ldw >= nb &&
+                   ldr >= ncols - (j + nb) && (Wn == nullptr || ldwn >= 1),
+               ROMA_E_SHAPE, "roma_chol_step: bad shape n=%d ncols=%d j=%d nb=%d B=%d", n, ncols, j, nb, B);
+  const int e = j + nb;
+  StepParams p{A, lda, strideA, n, ncols, j, nb, W, ldw, strideW, R, ldr, strideR, e < n ? Wn : nullptr, ldwn, strideWn, info, info_base, 0, 0};
+  p.ntr = (n - e + TS - 1) / TS;
+  p.ntc = (ncols - e + TS - 1) / TS;
+  if (p.ntc == 0) return 0;                                        // nothing to the right of the block
+  int tiles = p.ntc;                                               // R tiles
+  for (int I = 0; I < p.ntr; ++I) tiles += p.ntc - I;
+  hipLaunchKernelGGL(chol_step_kernel, dim3(tiles, B), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+  ROMA_CHECK_LAUNCH();
+}
+
+extern "C" int roma_chol_back_step(const float* W, int ldw, long strideW, float* R, long strideRb, long strideRs, int ldr, float* X,
+                                   int ldx, long strideX, int n, int m, int nb, int s, int B, void* stream) {
+  ROMA_REQUIRE(W && R && X, ROMA_E_ARG, "roma_chol_back_step: null pointer");
+  ROMA_REQUIRE(nb >= 1 && nb <= NBMAX && B >= 1 && n >= 1 && m >= 1 && s >= 0 && s * nb < n && ldw >= 1 && ldr >= 1 && ldx >= m,
+               ROMA_E_SHAPE, "roma_chol_back_step: bad shape n=%d m=%d nb=%d s=%d B=%d", n, m, nb, s, B);
+  ROMA_REQUIRE(nb == NBMAX || s == 0, ROMA_E_UNSUPPORTED, "roma_chol_back_step: block size %d (the update tiles assume 64-row blocks)", nb);
+  BackParams p{W, ldw, strideW, R, strideRb, strideRs, ldr, X, ldx, strideX, n, m, nb, s, (m + TS - 1) / TS};
+  hipLaunchKernelGGL(chol_back_kernel, dim3(p.ctiles * (1 + s), B), dim3(256), 0, static_cast<hipStream_t>(stream), p);
   ROMA_CHECK_LAUNCH();
 }

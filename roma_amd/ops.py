@@ -321,13 +321,13 @@ def spd_solve(K, F, nb=64, check="now"):
     """Solve K X = F for a batch of SPD matrices by a hand-blocked Cholesky: K (B,n,n) fp32, F (B,n,m) fp32.  Replaces
     `inv(K) @ F` of GP.forward (matcher.py:259-263).
 
-    Works on the augmented matrix A = [K | F] kept fully symmetric in its K part.  Per 64-wide block step s:
-      1. roma_chol_diag_block factors the diagonal block and also emits W = L_ss^-1;
-      2. ONE GEMM  R = W @ A[rows of the block, columns right of it] = [L_panel^T | Y_s]  (the transposed Cholesky panel and
-         the block's share of the forward substitution at once);
-      3. ONE GEMM  A[below, right] -= R_left^T @ R  (trailing update of K and of the right-hand sides together).
-    The forward substitution therefore never runs as a separate sweep; the backward one takes two GEMMs per block.
-    125 launches for n = 1600 instead of the 250 of the textbook three-sweep form.
+    Works on the augmented matrix A = [K | F].  Per 64-wide block step s ONE launch (roma_chol_step) computes the panel
+    R = W_s @ A[rows of the block, columns right of it] = [L_panel^T | Y_s] (the transposed Cholesky panel and the block's share of
+    the forward substitution at once), applies the trailing update A[below, right] -= R_left^T @ R to K and to the right-hand
+    sides together (tiles on or right of the diagonal only), and factors the NEXT diagonal block in the workgroup that just
+    produced it (W_{s+1} = L^-1 of that block).  Round 1 / early round 2 used a diagonal-block kernel + two library GEMMs per block
+    for this (75 launches) and two GEMMs per block for the backward substitution (50 launches), which is now one
+    roma_chol_back_step launch per block row: 51 launches of hand-written kernels, no library call, for n = 1600.
 
     A non-positive or NaN pivot (K not SPD: non-finite / degenerate features) is recorded by the kernel, which clamps it
     and carries on; check="now" reads that record back and raises like the reference's torch.linalg.inv does;
@@ -362,20 +362,25 @@ def _spd_solve(K, F, nb):
     steps = [(j, min(j + nb, n)) for j in range(0, n, nb)]
     W = torch.empty((B, len(steps), nb, nb), dtype=torch.float32, device=K.device)
     info = torch.zeros((B,), dtype=torch.int32, device=K.device)
-    R = []
+    # forward: one launch per block (roma_chol_step: panel r = W_s A[j:e, e:], trailing update, NEXT diagonal block factored in place)
+    Rall = torch.empty((B, len(steps), nb, n + m), dtype=torch.float32, device=K.device)
+    check(lib.roma_chol_diag_block(A.data_ptr(), A.stride(1), A.stride(0), W.data_ptr(), nb, W.stride(0), steps[0][1], B,
+                                   info.data_ptr(), 0, _stream()), "roma_chol_diag_block")
     for s, (j, e) in enumerate(steps):
-        w = e - j
-        check(lib.roma_chol_diag_block(A[:, j:e, j:e].data_ptr(), A.stride(1), A.stride(0), W[:, s].data_ptr(), nb, W.stride(0), w, B,
-                                       info.data_ptr(), 64 * s, _stream()), "roma_chol_diag_block")
-        r = torch.bmm(W[:, s, :w, :w], A[:, j:e, e:])             # (B, w, (n-e)+m) = [L[e:, j:e]^T | Y[j:e]]
-        R.append(r)
-        if e < n:
-            A[:, e:, e:].baddbmm_(r[:, :, :n - e].transpose(1, 2), r, alpha=-1.0)
+        last = s + 1 == len(steps)
+        check(lib.roma_chol_step(A.data_ptr(), A.stride(1), A.stride(0), n, n + m, j, e - j, W[:, s].data_ptr(), nb, W.stride(0),
+                                 Rall[:, s].data_ptr(), n + m, Rall.stride(0), None if last else W[:, s + 1].data_ptr(), nb, W.stride(0),
+                                 info.data_ptr(), nb * (s + 1), B, _stream()), "roma_chol_step")
     X = torch.empty((B, n, m), dtype=torch.float32, device=K.device)
-    for s in range(len(steps) - 1, -1, -1):                       # L^T X = Y, block rows from the bottom up
+    if nb == 64 or len(steps) == 1:
+        for s in range(len(steps) - 1, -1, -1):                   # L^T X = Y: one launch per block row, from the bottom up
+            check(lib.roma_chol_back_step(W[:, s].data_ptr(), nb, W.stride(0), Rall.data_ptr(), Rall.stride(0), Rall.stride(1), n + m,
+                                          X.data_ptr(), m, X.stride(0), n, m, nb, s, B, _stream()), "roma_chol_back_step")
+        return X, info
+    for s in range(len(steps) - 1, -1, -1):                       # other block sizes: two GEMMs per block row
         j, e = steps[s]
         w = e - j
-        r = R[s]
+        r = Rall[:, s, :w, :n + m - e]                            # (B, w, (n-e)+m) = [L[e:, j:e]^T | Y[j:e]]
         t = r[:, :, n - e:]
         if e < n:
             t = torch.baddbmm(t, r[:, :, :n - e], X[:, e:], alpha=-1.0)
