@@ -113,15 +113,20 @@ int roma_chol_diag_block(float* A, int lda, long strideA, float* W, int ldw, lon
 int roma_chol_step(float* A, int lda, long strideA, int n, int ncols, int j, int nb, const float* W, int ldw, long strideW, float* R,
                    int ldr, long strideR, float* Wn, int ldwn, long strideWn, int* info, int info_base, int B, void* stream);
 
-/* One fused step of the back substitution L^T X = Y of the same solve.  R holds ALL panels written by roma_chol_step: panel i of
- * matrix b starts at R + b*strideRb + i*strideRs (nb rows, leading dimension ldr) and is [L[e_i:, block i]^T | T_i] with
- * e_i = min((i+1) nb, n): n - e_i columns of the transposed Cholesky panel, then m columns that start as Y_i.  For block row s
- * (call with s = S-1 down to 0; W = the inverse factor of diagonal block s):
- *   X[s nb : s nb + w_s, :]  <-  W^T T_s                         (X: n x m, ldx, strideX)
- *   T_i  -=  L[block s, block i]^T X_s     for every i < s        (in place, in R)
- * nb = 64 (a single-block solve may use any nb <= 64).  One launch instead of the two GEMMs per block of the GEMM formulation. */
-int roma_chol_back_step(const float* W, int ldw, long strideW, float* R, long strideRb, long strideRs, int ldr, float* X, int ldx,
-                        long strideX, int n, int m, int nb, int s, int B, void* stream);
+/* One fused step of a triangular substitution with the finished factor of the same solve.  R holds ALL panels written by
+ * roma_chol_step: panel k of matrix b starts at R + b*strideRb + k*strideRs (nb rows, leading dimension ldr); its first
+ * n - e_k columns, e_k = min((k+1) nb, n), are L[e_k:, block k]^T.  T is the right-hand side, consumed in place: block row i of
+ * matrix b at T + b*strideTb + i*strideTs (leading dimension ldt), shifted by n - e_i columns when t_in_panel != 0 (the layout in
+ * which roma_chol_step leaves Y: T = R, strideTs = strideRs, ldt = ldr).  W = the inverse factor of diagonal block s.
+ *   dir < 0 (back substitution L^T X = T; call with s = S-1 down to 0):
+ *       X[s nb : s nb + w_s, :] <- W^T T_s;   T_i -= L[block s, block i]^T X_s  for every i < s
+ *   dir > 0 (forward substitution L Y = T for a NEW right-hand side — iterative refinement; call with s = 0 up to S-1):
+ *       X[s nb : s nb + w_s, :] <- W T_s;     T_i -= L[block i, block s] Y_s    for every i > s
+ * X: n x m, ldx, strideX.  nb = 64 (a single-block solve may use any nb <= 64).  One launch per block row instead of the two
+ * GEMMs of the GEMM formulation. */
+int roma_chol_subst_step(int dir, const float* W, int ldw, long strideW, const float* R, long strideRb, long strideRs, int ldr, float* T,
+                         long strideTb, long strideTs, int ldt, int t_in_panel, float* X, int ldx, long strideX, int n, int m, int nb,
+                         int s, int B, void* stream);
 
 /* match() post-processing — matcher.py:656-662, 684-718: certainty attenuation by the coarse scale-16 certainty,
  * sigmoid, zeroing where |flow|>1, clamp, symmetric concat.

@@ -32,8 +32,8 @@ SIGNATURES = {
     "roma_chol_diag_block": [c_void_p, c_int, c_long, c_void_p, c_int, c_long, c_int, c_int, c_void_p, c_int, c_void_p],
     "roma_chol_step": [c_void_p, c_int, c_long, c_int, c_int, c_int, c_int, c_void_p, c_int, c_long, c_void_p, c_int, c_long,
                        c_void_p, c_int, c_long, c_void_p, c_int, c_int, c_void_p],
-    "roma_chol_back_step": [c_void_p, c_int, c_long, c_void_p, c_long, c_long, c_int, c_void_p, c_int, c_long, c_int, c_int, c_int,
-                            c_int, c_int, c_void_p],
+    "roma_chol_subst_step": [c_int, c_void_p, c_int, c_long, c_void_p, c_long, c_long, c_int, c_void_p, c_long, c_long, c_int, c_int,
+                             c_void_p, c_int, c_long, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "roma_match_finalize": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "roma_kde_density": [c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p],
     "roma_nn_argmin": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],

@@ -335,56 +335,77 @@ __global__ __launch_bounds__(256) void chol_step_kernel(StepParams p) {
 }
 
 
-// ---- one fused step of the back substitution L^T X = Y (round 2) ---------------------------------------------------------------------
-// Block row s (from the last to the first): X_s = W_s^T T_s, then every block row i < s takes T_i -= L[s, i]^T X_s, where T_i starts as
-// the Y part of panel i and L[s, i]^T is the (rows of block i) x (columns of block s) piece of panel i (roma_chol_step's R).  One
-// launch per block row instead of two GEMMs: every (i, 64-column tile c) workgroup recomputes the X_s tile it needs (one 64^3
-// product; no workgroup waits for another) and applies its update; "X tiles" (one per c) store X_s.
-struct BackParams {
-  const float* W; int ldw; long strideW;                          // W_s
-  float* R; long strideRb, strideRs; int ldr;                     // all panels: panel i of matrix b at R + b*strideRb + i*strideRs
+// ---- one fused step of a triangular substitution with the finished factor (round 2) -----------------------------------------------
+// dir < 0, back substitution L^T X = T: block row s (from the last to the first): X_s = W_s^T T_s, then every block row i < s takes
+//   T_i -= L[s, i]^T X_s.
+// dir > 0, forward substitution L Y = T (a NEW right-hand side against the finished factor: iterative refinement): block row s
+//   (from the first to the last): Y_s = W_s T_s, then every block row i > s takes T_i -= L[i, s] Y_s.
+// L comes from the panels roma_chol_step wrote: panel k is L[e_k:, block k]^T (64 x (n - e_k)).  Right-looking, so one launch per
+// block row: every (i, 64-column tile c) workgroup recomputes the X_s / Y_s tile it needs (one 64^3 product; no workgroup waits for
+// another) and applies its update; "X tiles" (one per c) store X_s / Y_s.
+struct SubstParams {
+  const float* W; int ldw; long strideW;                          // W_s = inverse factor of diagonal block s
+  const float* R; long strideRb, strideRs; int ldr;               // panels: panel k of matrix b at R + b*strideRb + k*strideRs
+  float* T; long strideTb, strideTs; int ldt, t_in_panel;         // T_i at T + b*strideTb + i*strideTs (+ n - e_i columns if t_in_panel)
   float* X; int ldx; long strideX;
-  int n, m, nb, s, ctiles;
+  int n, m, nb, s, dir, nblk, ctiles;
 };
 
-__global__ __launch_bounds__(256) void chol_back_kernel(BackParams p) {
+__global__ __launch_bounds__(256) void chol_subst_kernel(SubstParams p) {
   __shared__ __attribute__((aligned(16))) float smem[3 * TS * TLD];
-  float* sW = smem;                                               // W_s, then L[s, i] ( = (panel piece)^T )
+  float* sW = smem;                                               // W_s (back) / W_s^T (forward), then the L piece
   float* sT = smem + TS * TLD;                                    // T_s tile
-  float* sX = smem + 2 * TS * TLD;                                // X_s tile
+  float* sX = smem + 2 * TS * TLD;                                // X_s / Y_s tile
   const int tid = threadIdx.x, b = blockIdx.y;
   int id = blockIdx.x, i = -1, c;
-  if (id < p.ctiles) c = id; else { id -= p.ctiles; i = id / p.ctiles; c = id - i * p.ctiles; }
+  if (id < p.ctiles) c = id;
+  else {
+    id -= p.ctiles;
+    i = id / p.ctiles;
+    c = id - i * p.ctiles;
+    if (p.dir > 0) i += p.s + 1;                                   // forward: the block rows below s
+  }
   const int js = p.s * p.nb, es = min(js + p.nb, p.n), ws = es - js;
   const float* Wb = p.W + (size_t)b * p.strideW;
-  float* Rb = p.R + (size_t)b * p.strideRb;
-  const float* Ts = Rb + (size_t)p.s * p.strideRs + (p.n - es);   // Y / T part of panel s
+  const float* Rb = p.R + (size_t)b * p.strideRb;
+  float* Tb = p.T + (size_t)b * p.strideTb;
+  const float* Ts = Tb + (size_t)p.s * p.strideTs + (p.t_in_panel ? p.n - es : 0);
   const int c0 = c * TS;
   const int t4r = (tid >> 4) * 4, t4c = (tid & 15) * 4;
   for (int idx = tid; idx < TS * TS; idx += 256) {
     const int k = idx >> 6, q = idx & 63;
-    sW[k * TLD + q] = (k < ws && q < ws) ? Wb[(size_t)k * p.ldw + q] : 0.f;
-    sT[k * TLD + q] = (k < ws && c0 + q < p.m) ? Ts[(size_t)k * p.ldr + c0 + q] : 0.f;
+    const float wv = (k < ws && q < ws) ? Wb[(size_t)k * p.ldw + q] : 0.f;
+    if (p.dir < 0) sW[k * TLD + q] = wv; else sW[q * TLD + k] = wv;   // product below sums over the FIRST index
+    sT[k * TLD + q] = (k < ws && c0 + q < p.m) ? Ts[(size_t)k * p.ldt + c0 + q] : 0.f;
   }
   __syncthreads();
-  // this workgroup's T_i tile and its piece of panel i: requested now, consumed after the first product
-  const int ei = (i + 1) * p.nb;                                   // i < s: block i is a full one
-  float* Pi = Rb + (size_t)(i < 0 ? 0 : i) * p.strideRs;          // panel i: [L[e_i:, block i]^T | T_i]
-  float* Ti = Pi + (p.n - ei);
+  // this workgroup's T_i tile and its piece of L: requested now, consumed after the first product
+  const int ji = (i < 0 ? 0 : i) * p.nb, ei = min(ji + p.nb, p.n), wi = ei - ji;
+  float* Ti = Tb + (size_t)(i < 0 ? 0 : i) * p.strideTs + (p.t_in_panel ? p.n - ei : 0);
   float told[4][4], lpiece[16];
   if (i >= 0) {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc)
-        told[r][cc] = (t4r + r < p.nb && c0 + t4c + cc < p.m) ? Ti[(size_t)(t4r + r) * p.ldr + c0 + t4c + cc] : 0.f;
+        told[r][cc] = (t4r + r < wi && c0 + t4c + cc < p.m) ? Ti[(size_t)(t4r + r) * p.ldt + c0 + t4c + cc] : 0.f;
+    if (p.dir < 0) {                                               // L[s, i][q][r] = panel_i[r][(js - e_i) + q]
+      const float* Pi = Rb + (size_t)i * p.strideRs;
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int idx = tid + 256 * u, r = idx >> 6, q = idx & 63;
-      lpiece[u] = (r < p.nb && q < ws) ? Pi[(size_t)r * p.ldr + (js - ei) + q] : 0.f;
+      for (int u = 0; u < 16; ++u) {
+        const int idx = tid + 256 * u, r = idx >> 6, q = idx & 63;
+        lpiece[u] = (r < wi && q < ws) ? Pi[(size_t)r * p.ldr + (js - ei) + q] : 0.f;
+      }
+    } else {                                                       // L[i, s][r][q] = panel_s[q][(ji - e_s) + r]
+      const float* Ps = Rb + (size_t)p.s * p.strideRs;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int idx = tid + 256 * u, q = idx >> 6, r = idx & 63;
+        lpiece[u] = (r < wi && q < ws) ? Ps[(size_t)q * p.ldr + (ji - es) + r] : 0.f;
+      }
     }
   }
-  f2_t x2[4][2];                                                   // X_s[q][col] = sum_k W_s[k][q] T_s[k][col]
+  f2_t x2[4][2];                                                   // X_s[q][col] = sum_k sW[k][q] T_s[k][col]
 #pragma unroll
   for (int r = 0; r < 4; ++r) x2[r][0] = x2[r][1] = f2_t{0.f, 0.f};
   tile_product(sW, sT, t4r, t4c, x2);
@@ -404,9 +425,10 @@ __global__ __launch_bounds__(256) void chol_back_kernel(BackParams p) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) *reinterpret_cast<float4_t*>(sX + (t4r + r) * TLD + t4c) = float4_t{xs[r][0], xs[r][1], xs[r][2], xs[r][3]};
 #pragma unroll
-  for (int u = 0; u < 16; ++u) {                                   // sW[q][r] = L[s, i][q][r] = panel_i[r][(js - e_i) + q]
-    const int idx = tid + 256 * u, r = idx >> 6, q = idx & 63;
-    sW[q * TLD + r] = lpiece[u];
+  for (int u = 0; u < 16; ++u) {                                   // sW[q][r] = (the L piece)[q][r]: the product sums over q
+    const int idx = tid + 256 * u;
+    if (p.dir < 0) sW[(idx & 63) * TLD + (idx >> 6)] = lpiece[u];  // loaded r-major
+    else sW[(idx >> 6) * TLD + (idx & 63)] = lpiece[u];            // loaded q-major
   }
   __syncthreads();
   f2_t acc2[4][2];
@@ -417,7 +439,7 @@ __global__ __launch_bounds__(256) void chol_back_kernel(BackParams p) {
   for (int r = 0; r < 4; ++r)
 #pragma unroll
     for (int cc = 0; cc < 4; ++cc)
-      if (t4r + r < p.nb && c0 + t4c + cc < p.m) Ti[(size_t)(t4r + r) * p.ldr + c0 + t4c + cc] = told[r][cc] - acc2[r][cc >> 1][cc & 1];
+      if (t4r + r < wi && c0 + t4c + cc < p.m) Ti[(size_t)(t4r + r) * p.ldt + c0 + t4c + cc] = told[r][cc] - acc2[r][cc >> 1][cc & 1];
 }
 
 }  // namespace
@@ -451,13 +473,18 @@ extern "C" int roma_chol_step(float* A, int lda, long strideA, int n, int ncols,
   ROMA_CHECK_LAUNCH();
 }
 
-extern "C" int roma_chol_back_step(const float* W, int ldw, long strideW, float* R, long strideRb, long strideRs, int ldr, float* X,
-                                   int ldx, long strideX, int n, int m, int nb, int s, int B, void* stream) {
-  ROMA_REQUIRE(W && R && X, ROMA_E_ARG, "roma_chol_back_step: null pointer");
-  ROMA_REQUIRE(nb >= 1 && nb <= NBMAX && B >= 1 && n >= 1 && m >= 1 && s >= 0 && s * nb < n && ldw >= 1 && ldr >= 1 && ldx >= m,
-               ROMA_E_SHAPE, "roma_chol_back_step: bad shape n=%d m=%d nb=%d s=%d B=%d", n, m, nb, s, B);
-  ROMA_REQUIRE(nb == NBMAX || s == 0, ROMA_E_UNSUPPORTED, "roma_chol_back_step: block size %d (the update tiles assume 64-row blocks)", nb);
-  BackParams p{W, ldw, strideW, R, strideRb, strideRs, ldr, X, ldx, strideX, n, m, nb, s, (m + TS - 1) / TS};
-  hipLaunchKernelGGL(chol_back_kernel, dim3(p.ctiles * (1 + s), B), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+extern "C" int roma_chol_subst_step(int dir, const float* W, int ldw, long strideW, const float* R, long strideRb, long strideRs, int ldr,
+                                    float* T, long strideTb, long strideTs, int ldt, int t_in_panel, float* X, int ldx, long strideX, int n,
+                                    int m, int nb, int s, int B, void* stream) {
+  ROMA_REQUIRE(W && R && T && X, ROMA_E_ARG, "roma_chol_subst_step: null pointer");
+  ROMA_REQUIRE(nb >= 1 && nb <= NBMAX && B >= 1 && n >= 1 && m >= 1 && s >= 0 && s * nb < n && ldw >= 1 && ldr >= 1 && ldt >= 1 &&
+                   ldx >= m && dir != 0,
+               ROMA_E_SHAPE, "roma_chol_subst_step: bad shape n=%d m=%d nb=%d s=%d B=%d dir=%d", n, m, nb, s, B, dir);
+  const int nblk = (n + nb - 1) / nb;
+  ROMA_REQUIRE(nb == NBMAX || nblk == 1, ROMA_E_UNSUPPORTED, "roma_chol_subst_step: block size %d (the update tiles assume 64-row blocks)", nb);
+  SubstParams p{W, ldw, strideW, R, strideRb, strideRs, ldr, T, strideTb, strideTs, ldt, t_in_panel, X, ldx, strideX, n, m, nb, s, dir, nblk,
+                (m + TS - 1) / TS};
+  const int others = dir < 0 ? s : nblk - 1 - s;
+  hipLaunchKernelGGL(chol_subst_kernel, dim3(p.ctiles * (1 + others), B), dim3(256), 0, static_cast<hipStream_t>(stream), p);
   ROMA_CHECK_LAUNCH();
 }

@@ -317,7 +317,7 @@ def raise_pending():
         _raise_if_not_spd(chk.result())
 
 
-def spd_solve(K, F, nb=64, check="now"):
+def spd_solve(K, F, nb=64, check="now", refine=0):
     """Solve K X = F for a batch of SPD matrices by a hand-blocked Cholesky: K (B,n,n) fp32, F (B,n,m) fp32.  Replaces
     `inv(K) @ F` of GP.forward (matcher.py:259-263).
 
@@ -327,7 +327,13 @@ def spd_solve(K, F, nb=64, check="now"):
     sides together (tiles on or right of the diagonal only), and factors the NEXT diagonal block in the workgroup that just
     produced it (W_{s+1} = L^-1 of that block).  Round 1 / early round 2 used a diagonal-block kernel + two library GEMMs per block
     for this (75 launches) and two GEMMs per block for the backward substitution (50 launches), which is now one
-    roma_chol_back_step launch per block row: 51 launches of hand-written kernels, no library call, for n = 1600.
+    roma_chol_subst_step launch per block row: 51 launches of hand-written kernels for n = 1600.
+
+    refine > 0: that many steps of iterative refinement follow — the residual F - K X in fp64 (one fp64 bmm) and the correction
+    through the finished factor (forward + back substitution, 2 x 25 launches, no second factorisation).  cond(K_yy) is ~1e4 on real
+    features, so a plain fp32 solve is good to ~1e-3 in Z; one step brings Z to 2e-4 of the fp64 solution OF THE SAME K.  Off by
+    default: once roma_cos_kernel delivers K entries good to 1e-6 the GP posterior is 2.1e-4 from the fp64 answer without it and
+    1.9e-4 with it (tools/gp_error_budget.py) — the K entries, not the solve, carry what error is left — and it costs 1 ms per match.
 
     A non-positive or NaN pivot (K not SPD: non-finite / degenerate features) is recorded by the kernel, which clamps it
     and carries on; check="now" reads that record back and raises like the reference's torch.linalg.inv does;
@@ -335,15 +341,15 @@ def spd_solve(K, F, nb=64, check="now"):
     check=None skips it.
 
     PYTORCH_TUNABLEOP_ENABLED=1: TunableOp's candidate sweep returned hipErrorInvalidValue for the in-place strided
-    trailing update of an earlier build (gpurun_out/bench_tune.err, round 1); the GEMMs of this routine therefore always
-    run with TunableOp switched off (restored afterwards)."""
+    trailing update of an earlier build (gpurun_out/bench_tune.err, round 1); the library calls left in this routine (the fp64
+    residual product, the GEMM fallback for nb != 64) therefore always run with TunableOp switched off (restored afterwards)."""
     _need_gpu(K, F)
     assert K.dtype == torch.float32 and F.dtype == torch.float32
     tun = torch.cuda.tunable.is_enabled()
     if tun:
         torch.cuda.tunable.enable(False)
     try:
-        X, info = _spd_solve(K, F, nb)
+        X, info = _spd_solve(K, F, nb, refine)
     finally:
         if tun:
             torch.cuda.tunable.enable(True)
@@ -354,7 +360,7 @@ def spd_solve(K, F, nb=64, check="now"):
     return X
 
 
-def _spd_solve(K, F, nb):
+def _spd_solve(K, F, nb, refine=0):
     B, n, _ = K.shape
     m = F.shape[2]
     lib = _lib.load()
@@ -373,9 +379,24 @@ def _spd_solve(K, F, nb):
                                  info.data_ptr(), nb * (s + 1), B, _stream()), "roma_chol_step")
     X = torch.empty((B, n, m), dtype=torch.float32, device=K.device)
     if nb == 64 or len(steps) == 1:
-        for s in range(len(steps) - 1, -1, -1):                   # L^T X = Y: one launch per block row, from the bottom up
-            check(lib.roma_chol_back_step(W[:, s].data_ptr(), nb, W.stride(0), Rall.data_ptr(), Rall.stride(0), Rall.stride(1), n + m,
-                                          X.data_ptr(), m, X.stride(0), n, m, nb, s, B, _stream()), "roma_chol_back_step")
+        S = len(steps)
+
+        def subst(direction, T, sTb, sTs, ldt, in_panel, out):
+            for s in (range(S - 1, -1, -1) if direction < 0 else range(S)):
+                check(lib.roma_chol_subst_step(direction, W[:, s].data_ptr(), nb, W.stride(0), Rall.data_ptr(), Rall.stride(0), Rall.stride(1),
+                                               n + m, T.data_ptr(), sTb, sTs, ldt, in_panel, out.data_ptr(), m, out.stride(0), n, m, nb, s, B,
+                                               _stream()), "roma_chol_subst_step")
+
+        subst(-1, Rall, Rall.stride(0), Rall.stride(1), n + m, 1, X)     # L^T X = Y: one launch per block row, from the bottom up
+        for _ in range(int(refine)):
+            # iterative refinement: residual in fp64 against the fp32-stored K, correction through the finished factor
+            # (forward + back substitution, 2 x S launches; no second factorisation)
+            g = (F.double() - torch.bmm(K.double(), X.double())).float().contiguous()
+            y = torch.empty_like(g)
+            subst(+1, g, g.stride(0), nb * m, m, 0, y)
+            d = torch.empty_like(g)
+            subst(-1, y, y.stride(0), nb * m, m, 0, d)
+            X = X + d
         return X, info
     for s in range(len(steps) - 1, -1, -1):                       # other block sizes: two GEMMs per block row
         j, e = steps[s]

@@ -322,7 +322,12 @@ def test_spd_solve_against_fp64():
         F = torch.randn(2, n, m)
         ref = solve64(K, F)
         X = _ops().spd_solve(K.to(DEV).contiguous(), F.to(DEV))
-        assert float((X.cpu().double() - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+        e0 = float((X.cpu().double() - ref).abs().max())
+        assert e0 < 2e-5 * float(ref.abs().max())
+        # one refinement step through the finished factor (forward + back substitution kernels, fp64 residual)
+        X1 = _ops().spd_solve(K.to(DEV).contiguous(), F.to(DEV), refine=1)
+        e1 = float((X1.cpu().double() - ref).abs().max())
+        assert e1 < 2e-6 * float(ref.abs().max()) and e1 <= e0
 
 
 # ---- match_finalize / kde ----------------------------------------------------------------------

@@ -76,7 +76,7 @@ def main():
     K = torch.exp((xn @ xn.transpose(1, 2) - 1) / 0.2) + 0.1 * torch.eye(1600, device="cuda")
     F = torch.randn(1, 1600, 512, device="cuda")
     t = timeit(lambda: ops.spd_solve(K, F, check=None), 10, 2)
-    print(f"spd_solve B=2 n=1600 m=512 (25 diagonal blocks + 100 GEMMs): {t*1e3:.3f} ms", flush=True)
+    print(f"spd_solve B=2 n=1600 m=512 (1 + 25 forward-step + 25 back-step launches): {t*1e3:.3f} ms", flush=True)
     A = K[:, :64, :64].contiguous()
     Wb = torch.empty(2, 64, 64, device="cuda")
     info = torch.zeros(2, dtype=torch.int32, device="cuda")

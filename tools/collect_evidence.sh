@@ -28,4 +28,10 @@ echo "[$(date +%T)] kernel microbench" | tee -a $O/progress.txt
 python3 tools/bench_kernels.py --pairs 1 > $O/kernels_microbench.txt 2>&1
 python3 tools/bench_kernels.py --pairs 1 --flow adversarial 2>&1 | grep local_corr >> $O/kernels_microbench.txt
 python3 tools/bench_kernels.py --pairs 16 2>&1 | grep -E "local_corr|dwconv" >> $O/kernels_microbench.txt
+echo "[$(date +%T)] bench lines" | tee -a $O/progress.txt
+python3 bench.py > $O/bench_line.json 2> $O/bench_line.err
+python3 bench.py --pairs 8 --no-cpu --no-microbench > $O/bench_pairs8.json 2>> $O/bench_line.err
+python3 bench.py --graph --no-cpu --no-microbench > $O/bench_graph.json 2>> $O/bench_line.err
+python3 bench.py --workload indoor_sample --no-cpu --no-microbench > $O/bench_indoor_sample.json 2>> $O/bench_line.err
+python3 bench.py --workload tiny --no-cpu --no-microbench > $O/bench_tiny.json 2>> $O/bench_line.err
 echo "[$(date +%T)] done" | tee -a $O/progress.txt

@@ -32,9 +32,9 @@ print("cond(Kyy)", float(torch.linalg.cond(Kyy64[0])), "|Z| max", float(Z64.abs(
 def err(mu): return float((mu.double() - mu64).abs().max())
 Kyy32, Kxy32 = ops.cos_kernel(ys, ys, T=T, diag_add=sig), ops.cos_kernel(xs, ys, T=T)
 print("K entry rel err: Kyy", float(((Kyy32.double() - Kyy64).abs() / Kyy64).max()), "Kxy", float(((Kxy32.double() - Kxy64).abs() / Kxy64).max()))
-ZA = ops.spd_solve(Kyy32, F)
+ZA = ops.spd_solve(Kyy32, F, refine=0)
 print("A  fp32-MFMA K, fp32 solve, fp32 bmm :", err(Kxy32 @ ZA))
-ZB = ops.spd_solve(Kyy64.float(), F)
+ZB = ops.spd_solve(Kyy64.float(), F, refine=0)
 print("F  as A but the product accumulated in fp64 (operands fp32)      :", err((Kxy32.double() @ ZA.double()).float()))
 print("B  K rounded from fp64, fp32 solve   :", err(Kxy64.float() @ ZB), " (Z err", float((ZB.double() - Z64).abs().max()), ")")
 print("B' as B but Kxy fp32-MFMA            :", err(Kxy32 @ ZB))
@@ -42,11 +42,21 @@ print("B2 Z exact(fp64->fp32), Kxy fp32-MFMA:", err(Kxy32 @ Z64.float()), "; Kxy
 # C: iterative refinement with an fp64 residual against the fp64-rounded-to-fp32 matrix
 K32 = Kyy64.float()
 r = (F.double() - K32.double() @ ZB.double()).float()
-ZC = ZB + ops.spd_solve(K32, r)
+ZC = ZB + ops.spd_solve(K32, r, refine=0)
 print("C  B + 1 refinement step (residual in fp64 against the fp32-stored K):", err(Kxy64.float() @ ZC), " Z err", float((ZC.double() - Z64).abs().max()))
 r = (F.double() - Kyy64 @ ZB.double()).float()
-ZD = ZB.double() + ops.spd_solve(K32, r).double()
+ZD = ZB.double() + ops.spd_solve(K32, r, refine=0).double()
 print("D  refinement against the fp64 K, Z kept fp64, mu = Kxy64 @ Z:", float((Kxy64 @ ZD - mu64).abs().max()))
+ZG = ops.spd_solve(Kyy32, F, refine=1)
+print("G  product path: fp32-MFMA K, fp32 solve + 1 refinement step through the finished factor, fp64-accumulated product:",
+      err((Kxy32.double() @ ZG.double()).float()), " Z err", float((ZG.double() - Z64).abs().max()))
+ZH = ops.spd_solve(Kyy32, F, refine=2)
+print("H  as G with 2 refinement steps:", err((Kxy32.double() @ ZH.double()).float()), " Z err", float((ZH.double() - Z64).abs().max()))
+for rf in (0, 1):
+    ZI = ops.spd_solve(Kyy64.float(), F, refine=rf)
+    print(f"I{rf} K_yy, K_xy rounded from fp64 (entry error 6e-8), fp32 solve + {rf} refinement, fp64-accumulated product:",
+          err((Kxy64.float().double() @ ZI.double()).float()), " Z err", float((ZI.double() - Z64).abs().max()))
+    print(f"J{rf} as I{rf} but K_xy from the fp32-MFMA kernel:", err((Kxy32.double() @ ZI.double()).float()))
 # torch's own fp32 paths for comparison
 Kt = torch.exp((torch.einsum("bnd,bmd->bnm", ys, ys) / (ys.norm(dim=-1)[..., None] * ys.norm(dim=-1)[:, None] + 1e-6) - 1) / T) + sig * I.float()
 Kxt = torch.exp((torch.einsum("bnd,bmd->bnm", xs, ys) / (xs.norm(dim=-1)[..., None] * ys.norm(dim=-1)[:, None] + 1e-6) - 1) / T)
