@@ -163,7 +163,7 @@ def parity_legs(device, dtype, pin, images):
         del m
         torch.cuda.empty_cache()
     tol = 1e-3
-    parity = dict(res["fp32"], mode="fp32", gp="fp32-MFMA CosKernel + blocked Cholesky (product kernels)", tolerance=tol,
+    parity = dict(res["fp32"], mode="fp32", gp="fp32-MFMA CosKernel (fp64 chunk sums / epilogue) + fused blocked Cholesky solve (product kernels)", tolerance=tol,
                   inputs="sacre_coeur_A/B.jpg" if images else "synthetic pair 0", weights="synthetic seed 0",
                   with_fp64_gp=res["fp32_gp64"])
     flips = int((arg["timed"] != arg["fp32"]).sum()) if arg["timed"] is not None and arg["fp32"] is not None else None
