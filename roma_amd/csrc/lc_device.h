@@ -25,6 +25,13 @@ __device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_wave_base) 
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc), "s"(lds_wave_base) : "memory");
 }
+// the same with the global address split into a wave-uniform base (SGPR pair) and a 32-bit per-lane byte offset: half the address
+// registers, and a per-chunk advance of the base is scalar work
+__device__ __forceinline__ void dma16_so(const void* sbase, uint32_t voff, uint32_t lds_wave_base) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_wave_base) : "memory");
+}
 __device__ __forceinline__ void dma4(const void* gsrc, uint32_t lds_wave_base) {
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"

@@ -915,7 +915,10 @@ int launch_any(const LCParams& p, hipStream_t s) {
       int v = p.variant;
       if (v == ROMA_LC_AUTO) v = (p.C % 32 == 0 && nt8 >= 2048) ? ROMA_LC_TILE8X8 : ROMA_LC_TILE8X4;
       const bool ring_ok = p.C % 32 == 0 && p.C >= kRingMinC;
-      if ((v == ROMA_LC_TILE8X8 && p.C % 32 == 0) || (v == ROMA_LC_RING && ring_ok)) {
+      // the 8x8-tile kernel addresses one feature map with 32-bit byte offsets
+      const bool t8_ok = p.C % 32 == 0 && (size_t)p.H * p.W * (size_t)(p.f0_pitch > p.f1_pitch ? p.f0_pitch : p.f1_pitch) * 2 < (1ull << 32);
+      if (v == ROMA_LC_TILE8X8 && !t8_ok) v = ROMA_LC_TILE8X4;
+      if (v == ROMA_LC_TILE8X8 || (v == ROMA_LC_RING && ring_ok)) {
         LCRingParams q{};
         q.f0 = p.f0; q.f1 = p.f1; q.flow = p.flow; q.out = p.out;
         q.B = p.B; q.C = p.C; q.H = p.H; q.W = p.W;

@@ -29,9 +29,9 @@ template <int R> struct T8Geom {
 };
 
 template <typename T, int R>
-__global__ __launch_bounds__(256, 3) void local_corr_t8_kernel(LCRingParams p) {
+__global__ __launch_bounds__(256, R <= 2 ? 4 : 3) void local_corr_t8_kernel(LCRingParams p) {
   using G = T8Geom<R>;
-  constexpr int N1 = 2 * R + 1, N2 = G::N2, Q = N2 * N2, K = N1 * N1, KP = K + 1;
+  constexpr int N1 = 2 * R + 1, N2 = G::N2, Q = N2 * N2, K = N1 * N1;
   constexpr int MAXR = G::MAXR, GHMAX = G::GHMAX, NB = GHMAX;
   constexpr int NL = ((kTP + MAXR) * 4 + 255) / 256;            // DMA rounds per chunk (64 rows each)
   constexpr int E16 = 8, CC = 32;
@@ -131,20 +131,22 @@ __global__ __launch_bounds__(256, 3) void local_corr_t8_kernel(LCRingParams p) {
     // =========================== matrix-core path ===========================
     const int nrows = bw * bh;
     const int nl_used = __builtin_amdgcn_readfirstlane((kTP + nrows + 63) >> 6);
-    const T* src[NL];
+    // DMA source plan: per-lane BYTE offsets from the (batch item's) f0 / f1 base — 32 bits (the host checks one map is < 4 GB),
+    // so 6 registers instead of 12, and the per-chunk channel advance is a scalar add on the base
+    uint32_t soff[NL];
     {
       const int prow = tid >> 2;
       const int kk8 = (((tid & 3) ^ ((tid >> 4) & 1))) * E16;
       int fpy, fpx;
       fpix(prow, fpy, fpx);
-      src[0] = f0 + ((size_t)min(ty0 + fpy, H - 1) * W + min(tx0 + fpx, W - 1)) * p.f0_pitch + kk8;
+      soff[0] = (uint32_t)(((size_t)min(ty0 + fpy, H - 1) * W + min(tx0 + fpx, W - 1)) * p.f0_pitch + kk8) * (uint32_t)sizeof(T);
       const float inv_bw = 1.0f / (float)max(bw, 1);
 #pragma unroll
       for (int l = 1; l < NL; ++l) {
         const int rr = (l - 1) * 64 + prow;
         const int ry = min((int)(((float)rr + 0.5f) * inv_bw), max(bh - 1, 0));     // rr / bw, exact for these small integers
         const int y = by0 + ry, x = bx0 + rr - ry * bw;
-        src[l] = rr < nrows ? f1 + ((size_t)y * W + x) * p.f1_pitch + kk8 : f1;    // slots past the box read a valid dummy
+        soff[l] = rr < nrows ? (uint32_t)(((size_t)y * W + x) * p.f1_pitch + kk8) * (uint32_t)sizeof(T) : 0u;   // slots past the box read a valid dummy
       }
     }
     const int g = wave;
@@ -166,35 +168,59 @@ __global__ __launch_bounds__(256, 3) void local_corr_t8_kernel(LCRingParams p) {
       acc[j] = float4_t{0.f, 0.f, 0.f, 0.f};
     }
     const uint32_t dbase = lds0 + (uint32_t)wave * 1024u;
+    constexpr int GQ = 4, NQ = (NB + GQ - 1) / GQ;                  // B fragments are read GQ at a time, one group ahead of the MFMAs
     for (int c0 = 0; c0 < p.C; c0 += CC) {
+      const T* b0 = f0 + c0;                                       // wave-uniform bases of this channel chunk
+      const T* b1 = f1 + c0;
+      dma16_so(b0, soff[0], dbase);
 #pragma unroll
-      for (int l = 0; l < NL; ++l)
-        if (l < nl_used) dma16(src[l] + c0, dbase + (uint32_t)(l * 4096));
+      for (int l = 1; l < NL; ++l)
+        if (l < nl_used) dma16_so(b1, soff[l], dbase + (uint32_t)(l * 4096));
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       raw_barrier();
       {
         const u32x4 a = rows[aidx];
-        u32x4 bf[NB];
+        u32x4 bq[2][GQ];
 #pragma unroll
-        for (int j = 0; j < NB; ++j) bf[j] = rows[bidx[j]];
-        __builtin_amdgcn_sched_barrier(0);
+        for (int t = 0; t < GQ; ++t) bq[0][t] = rows[bidx[t]];
 #pragma unroll
-        for (int j = 0; j < NB; ++j) acc[j] = mfma16r(a, bf[j], acc[j], T{});
+        for (int q = 0; q < NQ; ++q) {
+          if (q + 1 < NQ) {
+#pragma unroll
+            for (int t = 0; t < GQ; ++t)
+              if ((q + 1) * GQ + t < NB) bq[(q + 1) & 1][t] = rows[bidx[(q + 1) * GQ + t]];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int t = 0; t < GQ; ++t)
+            if (q * GQ + t < NB) acc[q * GQ + t] = mfma16r(a, bq[q & 1][t], acc[q * GQ + t], T{});
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
       raw_barrier();
     }
     // ---- epilogue, wave-private ----
-    float* s_V = s_D + g * 16 * (Q + 1);
     if (inner) {
+      // Every pixel of the group has its whole window inside the map and inside the group's union.  Lane (n16, kg) holds, for its
+      // four pixels 4 kg + r4, union column n16 of every union row j.  The 4-tap blend happens in registers (DPP shift for the
+      // right-hand tap, the next accumulator block for the lower one); what is left is a dynamic (row, column) selection per
+      // pixel, done through a wave-private LDS column image WITHOUT predicates or per-element address arithmetic: the lane writes
+      // its NB - 1 blended values of one pixel quad with immediate offsets, then lane (l16, kg) picks output kk = l16 + 16 it of
+      // pixel 4 kg + r4 from column (window origin + kk % N1), row (origin + kk / N1).  (Round 2's first version stored each
+      // value under a window predicate into a per-pixel image and walked it with an e / K loop: ~870 of the 1 309 VALU
+      // instructions of a tile-wave, profiles/r02_local_corr_pmc.md.)  The staging rows are dead after the chunk loop's last
+      // barrier, so the image lives there.
+      constexpr int NBm1 = NB - 1;                                  // odd (11 / 13 / 15): conflict-free lane stride
+      float* col = reinterpret_cast<float*>(rows) + g * (64 * NBm1);
       float axv[4], ayv[4];
-      int iy0[4], ixv[4];
+      int sxv[4], syv[4];
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
         const int r = g * 16 + 4 * kg + r4;
         axv[r4] = s_ax[r];
         ayv[r4] = s_ay[r];
-        ixv[r4] = gx0 + n16 - (s_x0[r] - R);
-        iy0[r4] = ((unsigned)ixv[r4] < (unsigned)N1) ? gy0 - (s_y0[r] - R) : -1000;
+        sxv[r4] = s_x0[r] - R - gx0;                               // window origin inside the union: 0 <= sx, sx + N1 <= 16
+        syv[r4] = s_y0[r] - R - gy0;                               //                                 0 <= sy, sy + N1 <= NB - 1
       }
 #pragma unroll
       for (int j = 0; j < NB; ++j)
@@ -203,20 +229,25 @@ __global__ __launch_bounds__(256, 3) void local_corr_t8_kernel(LCRingParams p) {
           const float d = acc[j][r4];
           acc[j][r4] = d + axv[r4] * (right_neighbour(d) - d);
         }
+      const size_t kstride = p.out_nhwc ? 1 : (size_t)H * W;
 #pragma unroll
-      for (int j = 0; j + 1 < NB; ++j)
+      for (int r4 = 0; r4 < 4; ++r4) {
 #pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-          const int iy = j + iy0[r4];
-          if ((unsigned)iy < (unsigned)N1)
-            s_V[(4 * kg + r4) * KP + iy * N1 + ixv[r4]] = acc[j][r4] + ayv[r4] * (acc[j + 1][r4] - acc[j][r4]);
+        for (int j = 0; j < NBm1; ++j) col[lane * NBm1 + j] = acc[j][r4] + ayv[r4] * (acc[j + 1][r4] - acc[j][r4]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // same wave: LDS ops are ordered; this only pins the compiler
+        const int mp = 4 * kg + r4;
+        const int y = ty0 + (g >> 1) * 4 + (mp >> 2), x = tx0 + (g & 1) * 4 + (mp & 3);
+        T* po = p.out_nhwc ? out + (((size_t)b * H + y) * W + x) * p.out_pitch : out + ((size_t)b * p.out_pitch * H + y) * W + x;
+        const float* pc = col + ((kg * 16 + sxv[r4]) * NBm1 + syv[r4]);
+#pragma unroll
+        for (int it = 0; it < (K + 15) / 16; ++it) {
+          const int kk = n16 + 16 * it;
+          if (kk < K) {
+            const int iy = kk / N1, ix = kk - iy * N1;
+            po[(size_t)kk * kstride] = from_f32<T>(pc[ix * NBm1 + iy] * p.scale);
+          }
         }
-      for (int e = lane; e < 16 * K; e += 64) {
-        int m, kk;
-        if (p.out_nhwc) { m = e / K; kk = e - m * K; } else { kk = e >> 4; m = e & 15; }
-        const int y = ty0 + (g >> 1) * 4 + (m >> 2), x = tx0 + (g & 1) * 4 + (m & 3);
-        const size_t o = p.out_nhwc ? (((size_t)b * H + y) * W + x) * p.out_pitch + kk : (((size_t)b * p.out_pitch + kk) * H + y) * W + x;
-        out[o] = from_f32<T>(s_V[m * KP + kk] * p.scale);
+        asm volatile("" ::: "memory");                             // the next quad's writes stay behind these reads
       }
       return;
     }
