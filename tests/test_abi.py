@@ -40,6 +40,21 @@ def test_argument_validation_needs_no_gpu():
     assert rc == -1 and b"null pointer" in lib.roma_last_error()
     rc = lib.roma_race_keys(None, None, None, 4, 0.05, 1, None)
     assert rc == -1
+    # the fused Cholesky solve (round 2): null pointers, then shapes, are rejected before anything touches a device
+    rc = lib.roma_chol_step(None, 8, 64, 8, 8, 0, 8, None, 8, 64, None, 8, 64, None, 8, 64, None, 0, 1, None)
+    assert rc == -1 and b"roma_chol_step: null pointer" in lib.roma_last_error()
+    buf = (ctypes.c_float * 4)()
+    a = ctypes.cast(buf, ctypes.c_void_p)
+    rc = lib.roma_chol_step(a, 8, 64, 8, 8, 0, 65, a, 8, 64, a, 8, 64, None, 8, 64, a, 0, 1, None)     # nb > 64
+    assert rc < 0 and b"bad shape" in lib.roma_last_error()
+    rc = lib.roma_chol_subst_step(-1, None, 8, 64, None, 64, 64, 8, None, 64, 64, 8, 1, None, 8, 64, 8, 8, 8, 0, 1, None)
+    assert rc == -1 and b"roma_chol_subst_step: null pointer" in lib.roma_last_error()
+    rc = lib.roma_chol_subst_step(0, a, 8, 64, a, 64, 64, 8, a, 64, 64, 8, 1, a, 8, 64, 8, 8, 8, 0, 1, None)   # dir == 0
+    assert rc < 0 and b"bad shape" in lib.roma_last_error()
+    rc = lib.roma_chol_subst_step(1, a, 32, 1024, a, 64, 64, 200, a, 64, 64, 200, 0, a, 8, 64, 100, 8, 32, 1, 1, None)   # 32-row blocks, 4 of them
+    assert rc < 0 and b"64-row blocks" in lib.roma_last_error()
+    rc = lib.roma_dwconv5x5_bn_relu(a, a, a, a, a, 1, 12, 4, 4, 1, 12, 12, None)                      # C not a multiple of 8
+    assert rc < 0 and b"multiples of 8" in lib.roma_last_error()
 
 
 def test_ops_refuse_cpu_tensors():
