@@ -2,7 +2,7 @@
 """bench.py — image-pairs/s of RegressionMatcher.match() at 560->864 on N MI355X (BASELINE.json metric), plus the
 HBM roofline of the local_correlation kernel, a CPU baseline timed on the same box and the parity of what is timed.
 
-    python bench.py --gpus N --steps K --warmup W [--workload outdoor|indoor_sample|tiny] [--pairs P]
+    python bench.py --gpus N --steps K --warmup W [--workload outdoor|coarse|indoor_sample|tiny] [--pairs P]
 
 N > 1: when WORLD_SIZE is not set, bench.py launches its own ranks (`python -m torch.distributed.run --nproc-per-node N
 bench.py ...`, one rank per GPU, as a child process) and relays rank 0's JSON line; under an external torchrun it is a
@@ -15,6 +15,7 @@ step     = one pass of the hot path over --pairs synthetic image pairs per GPU, 
 workloads (BASELINE.json configs):
   outdoor       configs[1] (default; configs[2] = the same with --pairs 8 --gpus 8): roma_outdoor 560->864 full
                 coarse-to-fine symmetric match, fp16 autocast semantics of the reference's GPU path
+  coarse        configs[0] on the GPU: the 560 x 560 coarse pass alone (upsample_preds = False; the reference's CPU-runnable case)
   indoor_sample configs[3]: roma_indoor (same architecture) 560->864, 8 pairs per step, + sample(num=10000) per pair
   tiny          configs[4]: tiny_roma_v1 (XFeat-topology backbone) on 256 pairs of 480x640 per step
 roofline = local_correlation: algorithmic bytes (f0+f1+flow+out) of its launches in the timed region / their
@@ -46,7 +47,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="outdoor", choices=["outdoor", "indoor_sample", "tiny"])
+    ap.add_argument("--workload", default="outdoor", choices=["outdoor", "coarse", "indoor_sample", "tiny"])
     ap.add_argument("--pairs", type=int, default=0, help="image pairs per GPU per step (weak scaling); 0 = the workload's default (1 / 8 / 256)")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16", "fp32"])
     ap.add_argument("--graph", action="store_true", help="replay ONE captured hipGraph per step instead of ~900 eager launches (measured: "
@@ -258,7 +259,7 @@ def make_workload(args, device, dtype, rank, P):
     """Returns (step_fn, config dict, model-ish handle, pinned parity inputs builder)."""
     import torch
     from roma_amd.synthetic import synthetic_pair
-    if args.workload in ("outdoor", "indoor_sample"):
+    if args.workload in ("outdoor", "coarse", "indoor_sample"):
         model = build_model(device, dtype)
         first = rank * P
         pairs = [synthetic_pair(first + i) for i in range(P)]
@@ -279,6 +280,12 @@ def make_workload(args, device, dtype, rank, P):
             step.eager = lambda: model.match_tensors(A_lo, B_lo, A_hi, B_hi)
             cfg = {"workload": "roma_outdoor 560->864 full coarse-to-fine symmetric match (BASELINE configs[1]; configs[2] = --pairs 8 --gpus 8)",
                    "launch": "one captured hipGraph per step (both HIP streams of the step inside it)" if graphed is not None else "eager launches"}
+        elif args.workload == "coarse":
+            model.upsample_preds = False                           # BASELINE configs[0]: the 560 x 560 coarse pass alone
+
+            def step():
+                return model.match_tensors(A_lo, B_lo)
+            cfg = {"workload": "roma_outdoor 560x560 coarse-only symmetric match (BASELINE configs[0], the reference's CPU-runnable case, on the GPU)"}
         else:
             it = [rank]
 
@@ -290,7 +297,7 @@ def make_workload(args, device, dtype, rank, P):
             cfg = {"workload": "roma_indoor 560->864 symmetric match + sample(num=10000) per pair (BASELINE configs[3]); roma_indoor is the "
                                "roma_outdoor architecture with other weights (model_zoo/__init__.py:54-73)", "sample_num": 10000,
                    "sample_mode": model.sample_mode}
-        cfg.update(coarse_res=560, upsample_res=864, weights=WEIGHTS_NOTE, inputs=INPUTS_NOTE)
+        cfg.update(coarse_res=560, upsample_res=None if args.workload == "coarse" else 864, weights=WEIGHTS_NOTE, inputs=INPUTS_NOTE)
         return step, cfg, model, (A_lo, B_lo, A_hi, B_hi)
     # tiny
     from roma_amd.tiny import TinyRoMa, XFeatBackbone
@@ -398,7 +405,7 @@ def main():
     torch.set_grad_enabled(False)
     t0 = time.time()
     torch.set_num_threads(host_cores())
-    P = args.pairs or {"outdoor": 1, "indoor_sample": 8, "tiny": 256}[args.workload]
+    P = args.pairs or {"outdoor": 1, "coarse": 1, "indoor_sample": 8, "tiny": 256}[args.workload]
     run, cfg, model, resident = make_workload(args, device, dtype, rank, P)
     log(f"[bench] rank {rank}: workload {args.workload} built in {time.time()-t0:.1f}s")
 
@@ -506,7 +513,7 @@ def main():
                    parallelism=f"pair-sharded x{world}, one ordered gather of (warp, certainty) to rank 0 per step ({args.wire} on the links)" if world > 1 else "single GPU")
         cfg.update(extra)
         line = {
-            "metric": "image-pairs/sec at 560->864" if args.workload != "tiny" else "image-pairs/sec at 480x640 (tiny_roma_v1)",
+            "metric": {"tiny": "image-pairs/sec at 480x640 (tiny_roma_v1)", "coarse": "image-pairs/sec at 560 (coarse only)"}.get(args.workload, "image-pairs/sec at 560->864"),
             "value": total_pairs / elapsed, "unit": "image-pairs/s",
             "n_gpus": n_distinct if rehearsal else world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {torch.float16: "fp16", torch.bfloat16: "bf16", torch.float32: "fp32"}[dtype],
