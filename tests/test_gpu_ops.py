@@ -455,6 +455,74 @@ def test_cos_kernel_reads_channels_last_slices_in_place():
     assert torch.equal(ops.cos_kernel(x, x, diag_add=0.1), ops.cos_kernel(x.float().contiguous(), x.float().contiguous(), diag_add=0.1))
 
 
+def test_chol_step_and_subst_step_against_torch():
+    """One fused forward step (roma_chol_step) and one substitution step in each direction (roma_chol_subst_step) against their
+    definitions in include/roma_hip.h, computed with torch in fp64: n = 200 (three full blocks + one of 8 rows), m = 24."""
+    from roma_amd import _lib
+    from roma_amd._lib import check
+    lib = _lib.load()
+    torch.manual_seed(3)
+    B, n, m, nb = 2, 200, 24, 64
+    x = torch.nn.functional.normalize(torch.randn(B, n, 32), dim=-1)
+    K = torch.exp((x @ x.transpose(1, 2) - 1) / 0.2) + 0.1 * torch.eye(n)
+    F = torch.randn(B, n, m)
+    A = torch.cat((K, F), dim=2).to(DEV).contiguous()
+    A0 = A.double().cpu()
+    st = torch.cuda.current_stream().cuda_stream
+    W = torch.zeros(B, 4, nb, nb, device=DEV)
+    R = torch.zeros(B, 4, nb, n + m, device=DEV)
+    info = torch.zeros(B, dtype=torch.int32, device=DEV)
+    check(lib.roma_chol_diag_block(A.data_ptr(), n + m, A.stride(0), W.data_ptr(), nb, W.stride(0), nb, B, info.data_ptr(), 0, st), "diag")
+    check(lib.roma_chol_step(A.data_ptr(), n + m, A.stride(0), n, n + m, 0, nb, W[:, 0].data_ptr(), nb, W.stride(0), R[:, 0].data_ptr(), n + m,
+                             R.stride(0), W[:, 1].data_ptr(), nb, W.stride(0), info.data_ptr(), nb, B, st), "step")
+    torch.cuda.synchronize()
+    L00 = torch.linalg.cholesky(A0[:, :nb, :nb])
+    W0 = torch.linalg.inv(L00)
+    assert float((W[:, 0].double().cpu() - W0).abs().max()) < 1e-4
+    Rref = W0 @ A0[:, :nb, nb:]                                           # (B, 64, n - 64 + m)
+    assert float((R[:, 0, :, :n + m - nb].double().cpu() - Rref).abs().max()) < 1e-4
+    T = A0[:, nb:, nb:] - Rref[:, :, :n - nb].transpose(1, 2) @ Rref      # trailing update, full (the kernel keeps tiles J >= I)
+    got = A.double().cpu()[:, nb:, nb:]
+    for i0 in range(0, n - nb, 64):                                       # tiles on or right of the diagonal
+        i1 = min(i0 + 64, n - nb)
+        if i0 == 0:                                                       # next diagonal block: factored in place (lower), W_1 = L^-1
+            L11 = torch.linalg.cholesky(T[:, :64, :64])
+            assert float((torch.tril(got[:, :64, :64]) - L11).abs().max()) < 1e-4
+            assert float((W[:, 1].double().cpu() - torch.linalg.inv(L11)).abs().max()) < 2e-4
+            assert float((got[:, i0:i1, 64:] - T[:, i0:i1, 64:]).abs().max()) < 1e-4
+        else:
+            assert float((got[:, i0:i1, i0:] - T[:, i0:i1, i0:]).abs().max()) < 1e-4
+    assert int(info.abs().max()) == 0
+    # substitution steps on a synthetic factor: panels P_k = L[e_k:, block k]^T, W_k = inv(L_kk)
+    Lf = torch.linalg.cholesky(A0[:, :n, :n])
+    S = 4
+    Wall = torch.zeros(B, S, nb, nb, dtype=torch.float64)
+    Pall = torch.zeros(B, S, nb, n + m, dtype=torch.float64)
+    for k in range(S):
+        j, e = k * nb, min((k + 1) * nb, n)
+        Wall[:, k, :e - j, :e - j] = torch.linalg.inv(Lf[:, j:e, j:e])
+        Pall[:, k, :e - j, :n - e] = Lf[:, e:, j:e].transpose(1, 2)
+    Wd, Pd = Wall.float().to(DEV), Pall.float().to(DEV)
+    G = torch.randn(B, n, m)
+    for direction, s_blk in ((+1, 1), (-1, 2)):
+        Td = G.clone().to(DEV).contiguous()
+        Xd = torch.zeros(B, n, m, device=DEV)
+        check(lib.roma_chol_subst_step(direction, Wd[:, s_blk].data_ptr(), nb, Wd.stride(0), Pd.data_ptr(), Pd.stride(0), Pd.stride(1), n + m,
+                                       Td.data_ptr(), Td.stride(0), nb * m, m, 0, Xd.data_ptr(), m, Xd.stride(0), n, m, nb, s_blk, B, st), "subst")
+        torch.cuda.synchronize()
+        js, es = s_blk * nb, min((s_blk + 1) * nb, n)
+        Ws = Wall[:, s_blk, :es - js, :es - js]
+        Gs = G.double()[:, js:es]
+        Xs = (Ws @ Gs) if direction > 0 else (Ws.transpose(1, 2) @ Gs)
+        assert float((Xd.double().cpu()[:, js:es] - Xs).abs().max()) < 1e-4
+        Tref = G.double().clone()
+        if direction > 0:
+            Tref[:, es:] -= Lf[:, es:, js:es] @ Xs                        # T_i -= L[i, s] Y_s for i > s
+        else:
+            Tref[:, :js] -= Lf[:, js:es, :js].transpose(1, 2) @ Xs        # T_i -= L[s, i]^T X_s for i < s
+        assert float((Td.double().cpu() - Tref).abs().max()) < 1e-4
+
+
 # ---- spd_solve robustness ------------------------------------------------------------------------
 def test_spd_solve_raises_on_a_matrix_that_is_not_positive_definite():
     from roma_amd._lib import RomaHipError
