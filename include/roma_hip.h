@@ -128,6 +128,16 @@ int roma_chol_subst_step(int dir, const float* W, int ldw, long strideW, const f
                          long strideTb, long strideTs, int ldt, int t_in_panel, float* X, int ldx, long strideX, int n, int m, int nb,
                          int s, int B, void* stream);
 
+/* Multi-head attention forward, softmax(q k^T * scale) v, for the transformers of the path (DINOv2 blocks,
+ * romatch/models/transformer/layers/attention.py:48-60; the decoder transformer, transformer/__init__.py:30-46): fp16 / bf16, head
+ * dimension 64, no mask except "the first Nk tokens are keys / values" (the callers row-pad the sequence; padded tokens query only).
+ * q, k, v, o are addressed as base + b*sb + token*sn + head*sh (element strides; each a multiple of 8, bases 16-byte aligned), so
+ * the (B, N, 3, H, 64) output of the qkv projection is read in place and o can be the (B, N, H*64) input of the output projection.
+ * Flash-style (no Nq x Nk matrix), fp32 softmax statistics, P rounded to the storage dtype before the second product. */
+int roma_attention_fwd(const void* q, const void* k, const void* v, void* o, int B, int H, int Nq, int Nk, int head_dim, long q_sb,
+                       long q_sn, long q_sh, long k_sb, long k_sn, long k_sh, long v_sb, long v_sn, long v_sh, long o_sb, long o_sn,
+                       long o_sh, float scale, int dtype, void* stream);
+
 /* match() post-processing — matcher.py:656-662, 684-718: certainty attenuation by the coarse scale-16 certainty,
  * sigmoid, zeroing where |flow|>1, clamp, symmetric concat.
  *   flow (2P,2,H,W), cert (2P,1,H,W) fp32 planar: first P = A->B, last P = B->A (forward_symmetric, matcher.py:516-528)

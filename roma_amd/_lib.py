@@ -29,6 +29,7 @@ SIGNATURES = {
                         c_float, c_void_p],
     "roma_add_layernorm": [c_void_p, c_int, c_long, c_void_p, c_int, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_long,
                            c_long, c_int, c_float, c_void_p],
+    "roma_attention_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int] + [c_long] * 12 + [c_float, c_int, c_void_p],
     "roma_chol_diag_block": [c_void_p, c_int, c_long, c_void_p, c_int, c_long, c_int, c_int, c_void_p, c_int, c_void_p],
     "roma_chol_step": [c_void_p, c_int, c_long, c_int, c_int, c_int, c_int, c_void_p, c_int, c_long, c_void_p, c_int, c_long,
                        c_void_p, c_int, c_long, c_void_p, c_int, c_int, c_void_p],

@@ -600,6 +600,26 @@ def pointwise_small(x_rows, wt, bias, out=None):
     return out
 
 
+def attention(qkv, n_valid=None, out=None):
+    """softmax(q k^T / sqrt(d)) v for every head — attention.py:48-60 — straight from the qkv projection's output.
+    qkv: (B, N, 3, H, 64) fp16 / bf16, contiguous; keys / values are the first n_valid tokens (row padding beyond them queries but is
+    never attended to).  Returns (B, N, H*64), the input layout of the output projection."""
+    _need_gpu(qkv, out)
+    B, N, three, H, d = qkv.shape
+    assert three == 3 and qkv.is_contiguous()
+    if out is None:
+        out = torch.empty((B, N, H * d), dtype=qkv.dtype, device=qkv.device)
+    assert out.is_contiguous() and out.shape == (B, N, H * d) and out.dtype == qkv.dtype
+    es = qkv.element_size()
+    sb, sn, sh = qkv.stride(0), qkv.stride(1), qkv.stride(3)
+    base = qkv.data_ptr()
+    step = qkv.stride(2) * es
+    check(_lib.load().roma_attention_fwd(base, base + step, base + 2 * step, out.data_ptr(), B, H, N, N if n_valid is None else int(n_valid), d,
+                                         sb, sn, sh, sb, sn, sh, sb, sn, sh, out.stride(0), out.stride(1), d, float(d) ** -0.5, _dt(qkv),
+                                         _stream()), "roma_attention_fwd")
+    return out
+
+
 def add_layernorm(x, y, ln_weight, ln_bias, eps, out_dtype, ls=None):
     """x <- x + ls*y (in place, x's dtype; y None: no add); returns LayerNorm(x)*w+b cast to out_dtype (ln_weight None: just
     the cast).  x (..., C) contiguous rows; the seam between two transformer half-blocks (transformer/layers/block.py:87-107)."""

@@ -723,3 +723,21 @@ def test_pointwise_mfma_vs_torch(C, kpad, M, dtype):
     ref = x.float() @ wtd.float()[:C, :C].t() + bias[:C].to(DEV)
     tol = (2 ** -10 if dtype == torch.float16 else 2 ** -7) * max(1.0, float(ref.abs().max()))
     assert maxerr(out, ref) <= tol
+
+
+# ---- attention ------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,N,nv,Hh", [(2, 1664, 1601, 16), (1, 128, None, 2), (2, 200, 137, 3), (1, 77, 77, 1), (1, 64, 3, 1)])
+def test_attention_vs_torch_sdpa(dtype, B, N, nv, Hh):
+    """ops.attention (flash-style HIP kernel reading q/k/v in place from the qkv projection's output) against fp32 softmax attention on the
+    same rounded operands: the DINOv2 shape (1 601 real tokens row-padded to 1 664), ragged sizes, fewer keys than one tile."""
+    g = torch.Generator().manual_seed(N * 7 + Hh)
+    qkv = (torch.randn(B, N, 3, Hh, 64, generator=g) * 1.5).to(dtype).to(DEV)
+    out = _ops().attention(qkv, nv)
+    q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3).float() for i in range(3))                    # (B, H, N, 64)
+    n = N if nv is None else nv
+    p = torch.softmax(q @ k[:, :, :n].transpose(-1, -2) * 64 ** -0.5, dim=-1)
+    ref = (p @ v[:, :, :n]).permute(0, 2, 1, 3).reshape(B, N, Hh * 64)
+    tol = 4e-3 if dtype == torch.float16 else 3e-2
+    assert out.shape == ref.shape and out.dtype == dtype
+    assert maxerr(out, ref) < tol * max(1.0, float(ref.abs().max()))
