@@ -23,7 +23,8 @@ from . import ops
 # 16-bit modes instead of torch's scaled_dot_product_attention.  Opt-in for now: it is as accurate as SDPA against an fp64 attention
 # (identical max / rms error on every shape tried) and as fast at one pair per step (59.6 vs 62.5 us per layer; 345 vs 320 us at 8 pairs),
 # but the end-to-end fp16 statistics moved with it (32 instead of 17 of 3 200 coarse arg-max flips against the fp32 mode at 560 -> 864;
-# the GP amplifies any change of the 16-bit rounding noise), and that is not understood well enough to change the default.
+# torch's `math` SDPA backend, a third realisation of the same 16-bit noise, gives 34 — the GP amplifies any change of that noise), and
+# the fp16 statistics pinned in the tests / DESIGN.md §4 belong to the SDPA realisation.
 ATTENTION_KERNEL = os.environ.get("ROMA_ATTENTION", "sdpa") == "hip"
 
 
