@@ -116,6 +116,16 @@ def main():
     for exact in (False, True):
         t = timeit(lambda: ops.tiny_corr_posembed(f0, f1, exact=exact), iters=5, warm=2)
         print(f"tiny_corr_posembed B=16 60x80 C=64 exact={exact}: {t*1e3:.3f} ms  {2*16*4800*4800*64/t/1e12:.1f} TFLOP/s (fp32 MFMA), {16/t:.0f} pairs/s")
+    if dt != torch.float32:
+        import torch.nn.functional as F
+        for Ba in (B, 16):
+            qkv = torch.randn(Ba, 1664, 3, 16, 64, device="cuda").to(dt)
+            o = torch.empty(Ba, 1664, 1024, device="cuda", dtype=dt)
+            t = timeit(lambda: ops.attention(qkv, 1601, out=o), iters=20)
+            pp = qkv.permute(2, 0, 3, 1, 4)
+            t2 = timeit(lambda: F.scaled_dot_product_attention(pp[0], pp[1][:, :, :1601], pp[2][:, :, :1601]), iters=20)
+            fl = 4 * Ba * 16 * 1664 * 1601 * 64
+            print(f"attention B={Ba} 16 heads x 64, 1664 queries x 1601 keys: {t*1e6:.1f} us  {fl/t/1e12:.0f} TFLOP/s   (torch SDPA: {t2*1e6:.1f} us)", flush=True)
     pts = torch.rand(40000, 4, device="cuda") * 2 - 1
     t = timeit(lambda: ops.kde(pts, half=True), iters=5, warm=1)
     print(f"kde N=40000: {t*1e3:.3f} ms  {40000*40000/t/1e12:.2f} T pair-exp/s")
