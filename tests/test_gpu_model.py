@@ -277,6 +277,33 @@ def test_end_to_end_fp16_mode_bulk_agreement(full_model):
     assert float(dw.median()) < 1e-5 and p99 < 3e-5 and float(dc.max()) < 2e-2
 
 
+def test_fp16_mode_with_the_hand_written_attention_kernel(full_model):
+    """The opt-in DINOv2 attention kernel (ROMA_ATTENTION=hip -> roma_attention_fwd) inside the whole fp16 pipeline, 112 -> 168: the
+    DINOv2 features agree with the SDPA path at the level of the 16-bit noise, and the match agrees in bulk (a flipped coarse
+    arg-max moves 1/64 of this small map: bound on the bulk, as in test_end_to_end_fp16_mode_bulk_agreement)."""
+    import roma_amd.transformer as TR
+    _set_dtype(full_model, torch.float16)
+    try:
+        x = torch.randn(2, 3, 112, 112, generator=torch.Generator().manual_seed(11)).to(DEV)
+        TR.ATTENTION_KERNEL = False
+        f_sdpa = full_model.encoder.vit_features(x).float()
+        w_sdpa, c_sdpa = full_model.match(H.asset("sacre_coeur_A.jpg"), H.asset("sacre_coeur_B.jpg"), device=DEV)
+        TR.ATTENTION_KERNEL = True
+        f_hip = full_model.encoder.vit_features(x).float()
+        w_hip, c_hip = full_model.match(H.asset("sacre_coeur_A.jpg"), H.asset("sacre_coeur_B.jpg"), device=DEV)
+    finally:
+        TR.ATTENTION_KERNEL = False
+        _set_dtype(full_model, torch.float32)
+    rel = float((f_hip - f_sdpa).pow(2).mean().sqrt() / f_sdpa.pow(2).mean().sqrt())
+    dw = (w_hip - w_sdpa).abs()
+    moved = float((dw > 1e-3).float().mean())
+    print(f"hip vs sdpa attention: feature rms difference {rel:.2e} of the feature rms; warp entries moved > 1e-3: {moved:.3f}; "
+          f"certainty max diff {float((c_hip - c_sdpa).abs().max()):.2e}")
+    assert torch.isfinite(w_hip).all() and torch.isfinite(c_hip).all()
+    assert rel < 5e-3                                              # measured 1.4e-3 (the fp16 noise itself is 1.8e-3 of the fp32 features)
+    assert float(dw.median()) < 1e-5 and moved <= 6 / 64 and float((c_hip - c_sdpa).abs().max()) < 3e-2
+
+
 def test_batched_pairs_equal_per_pair_results(full_model):
     """Stack-of-per-pair semantics: P=2 pairs in one call == each pair alone (bit for bit in fp32)."""
     _set_dtype(full_model, torch.float32)
