@@ -1,4 +1,4 @@
-// Device helpers shared by the 8x8-tile local_correlation kernels (local_corr_ring.hip, local_corr_t8.hip).
+// Device helpers shared by the 8x8-tile local_correlation kernels (local_corr_t8.hip, local_corr_rows.hip).
 #pragma once
 #include "common.h"
 

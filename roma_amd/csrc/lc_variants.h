@@ -1,0 +1,27 @@
+// Interface between local_corr.hip (dispatch) and the tile kernels for 16-bit channels-last inputs with r <= 3
+// (local_corr_t8.hip: 8x8 tiles, 32-channel chunks; local_corr_rows.hip: box rows streamed whole, f0 in registers).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace roma {
+
+struct LCTileParams {
+  const void* f0;
+  const void* f1;
+  const float* flow;
+  void* out;
+  int B, C, H, W;
+  int f0_pitch, f1_pitch, out_pitch;
+  int out_nhwc;
+  int tiles_x, tiles_y;
+  int f1_shift;
+  float scale;
+};
+
+// one 8x8 tile per workgroup (local_corr_t8.hip): 16-bit channels-last inputs, r in 1..3, C a multiple of 32
+int local_corr_t8(const LCTileParams& p, int r, int dtype, hipStream_t stream);
+// row-streaming kernel (local_corr_rows.hip): 16-bit channels-last inputs, r in 1..3, C = 256 or 512; tile_h = 8 or 16
+bool local_corr_rows_supports(int C);
+int local_corr_rows(const LCTileParams& p, int r, int dtype, int tile_h, hipStream_t stream);
+
+}  // namespace roma

@@ -1,0 +1,500 @@
+// local_correlation, fp16 / bf16 channels-last, r <= 3, C = 256 or 512: the ROW-STREAMING kernel (round 3).
+// Reference: romatch/utils/local_correlation.py:4-48 (called at matcher.py:121-125); formulation as in local_corr.hip:
+// corr[p][iy][ix] = 4-tap blend of D[p][j][i] = <f0[p], f1[y0-r+j][x0-r+i]> on the (2r+2)^2 integer patch.
+//
+// Why another kernel (profiles/r02_local_corr_pmc.md, gpurun_out/r3_stage_micro.txt): the 32-channel-chunk kernels are bound by the
+// L2 -> LDS staging path, and tools/stage_micro.hip measured what that path can do on the same box of the same map: 64-byte pieces
+// per pixel (what the chunk kernels request) 10.4-12.1 TB/s, whole 512-byte pixel rows 14.1 TB/s, and 15.6-16.0 TB/s once a ring
+// keeps two stages in flight across the barrier — against the 7.2 TB/s the chunk kernels reach, whose every chunk is
+// issue -> wait for all of it -> barrier -> compute -> barrier.  So here
+//   * a stage is one ROW of the tile's f1 box: bw pixels x 256 channels, every pixel a contiguous 512-byte request, DMA'd into a
+//     4-slot LDS ring, two stages in flight behind a counted vmcnt, ONE barrier per stage;
+//   * f0 never touches LDS: wave g owns the 4x4-pixel group g and holds its 16 x C operand in registers (32 / 64 VGPRs), loaded
+//     straight from global memory before the flow is even read.  Because A comes from registers the K order is free, and lane
+//     quarter kg takes channels [64 kg, 64 kg + 64): with the 16-byte pieces of a staged pixel XOR-swizzled by (pixel & 7) inside
+//     each 128-byte quarter, the B-fragment ds_read_b128 of 16 consecutive pixels is conflict-free for any first pixel;
+//   * the K loop runs over the whole channel block inside a stage, so one (group, row) accumulator is complete when its stage is
+//     done: x-blend by a DPP shift, y-blend against the previous row kept in 4 registers, and the result goes straight into the
+//     group's [16 pixels][K] output image in LDS (a dump slot takes what falls outside a pixel's window: no exec juggling) —
+//     8 accumulator registers instead of 48-64, and the box may be as tall as it likes;
+//   * image borders need no second code path: out-of-image box columns are staged from a clamped address and zeroed by a select,
+//     out-of-image rows are not staged at all (the previous-row registers start at zero; one virtual row below the image).
+// Tiles whose targets are not compact (box wider than BWMAX, a group wider than 16 columns) take per-pixel patches on the VALU as in
+// the other kernels.  Tile = 8 x TH pixels, TH = 8 (4 waves) or 16 (8 waves: 3.0 instead of 3.9 staged f1 rows per pixel).
+#include "common.h"
+#include "lc_device.h"
+#include "lc_variants.h"
+
+namespace roma {
+namespace {
+
+using namespace lc;
+
+template <int R> struct SlowGeom {
+  static constexpr int N2 = 2 * R + 2, Q = N2 * N2, QP = Q;
+  static constexpr int NIT = (Q + 15) / 16;
+  static constexpr int SB = R <= 2 ? 8 : 4;                    // pixels per pass
+  static constexpr int UB = (SB * NIT + 15) / 16;
+  static constexpr int USED = kTP + SB * QP;                   // f0 rows + patches (64-byte rows)
+  static constexpr int SNL = (USED * 4 + 255) / 256;           // DMA rounds per chunk: 64 rows each, whole rounds are written
+  static constexpr int ZROW = SNL * 64;                        // first all-zero row, behind everything the DMA touches
+  static constexpr int ROWS = ZROW + 16;
+};
+
+template <int R, int NW> struct RowsGeom {
+  static constexpr int N1 = 2 * R + 1, K = N1 * N1;
+  static constexpr int BWMAX = 20;                             // widest staged box (pixels)
+  static constexpr int SLOTB = BWMAX * 512;                    // one stage: BWMAX pixels x 256 channels
+  static constexpr int NS = 4;                                 // ring slots; NS - 2 stages in flight beside the one being read
+  static constexpr int PF = NS - 2;
+  static constexpr int RINGB = NS * SLOTB;
+  static constexpr int NIT = SLOTB / 1024;                     // DMA wave-instructions per stage (two pixels each)
+  static constexpr int NIW = (NIT + NW - 1) / NW;
+  // Output image of one group: [17 pixel slots][N1 + 2 rows][N1] elements.  A lane writes one element per accumulator row for EVERY
+  // box row the group walks: window row tt = ya - (y0 - r) - 1 clamped to [-1, N1], so rows 0 and N1 + 1 of a slot collect what
+  // lies above / below the pixel's window, and slot 16 takes the lanes whose box column is outside the pixel's window.
+  static constexpr int TR = N1 + 2;
+  static constexpr int PPB = TR * N1 * 2;                      // bytes per pixel slot
+  static constexpr int OTB = ((17 * PPB + 15) / 16) * 16;
+  static constexpr int NPIX = 16 * NW;
+  static constexpr int SROWB = SlowGeom<R>::ROWS * 64, SDB = kTP * (SlowGeom<R>::Q + 1) * 4;
+  static constexpr int REGA = RINGB > SROWB + SDB ? RINGB : SROWB + SDB;   // ring | the patch path's rows + window images
+  static constexpr int REGB = NW * OTB;                        // output images
+  static constexpr int SMEM = REGA + REGB + 4 * NPIX * 4 + NW * 8 * 4;
+  static constexpr int MAXROWS = 96;                           // tallest box that still streams (beyond: patches)
+};
+
+// ---- incoherent 8x8 sub-tile: per-pixel patches on the VALU (the chunk kernels' path; 256 threads, the others only keep the
+// barrier count).  s_* point at the sub-tile's 64 entries, group-major.
+template <typename T, int R>
+__device__ __forceinline__ void slow_subtile(const LCTileParams& p, unsigned char* region, unsigned char* region_d, const int* s_x0, const int* s_y0,
+                                             const float* s_ax, const float* s_ay, int tid, int wave, int lane, bool active,
+                                             int b, int ty0, int tx0, const T* f0, const T* f1, T* out) {
+  using S = SlowGeom<R>;
+  constexpr int N1 = 2 * R + 1, N2 = S::N2, Q = S::Q, K = N1 * N1, QP = S::QP, NIT = S::NIT, SB = S::SB, UB = S::UB, SNL = S::SNL;
+  constexpr int ZROW = S::ZROW, E16 = 8, CC = 32;
+  const int H = p.H, W = p.W;
+  u32x4* rows = reinterpret_cast<u32x4*>(region);
+  float* s_D = reinterpret_cast<float*>(region_d);
+  const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)region;
+  int g16 = 0, idx = 0;                                         // 16-lane ds_read_b128 service groups of a wavefront
+  {
+    const int l5 = lane & 31;
+    int hg;
+    if (l5 < 4) { hg = 0; idx = l5; }
+    else if (l5 < 12) { hg = 1; idx = l5 - 4; }
+    else if (l5 < 16) { hg = 0; idx = l5 - 8; }
+    else if (l5 < 20) { hg = 1; idx = l5 - 8; }
+    else if (l5 < 28) { hg = 0; idx = l5 - 12; }
+    else { hg = 1; idx = l5 - 16; }
+    g16 = wave * 4 + (lane >> 5) * 2 + hg;
+  }
+  if (active) {
+    for (int i = tid; i < 64; i += 256) rows[ZROW * 4 + i] = u32x4{0, 0, 0, 0};
+    for (int i = tid; i < kTP * (Q + 1); i += 256) s_D[i] = 0.f;
+  }
+  __syncthreads();
+  for (int pass = 0; pass < kTP / SB; ++pass) {
+    int pixw[UB], qw[UB], rowidx[UB];
+    float sacc[UB];
+    const T* ssrc[SNL];
+    constexpr int used_rows = S::USED;
+    if (active) {
+#pragma unroll
+      for (int w = 0; w < UB; ++w) {
+        const int uu = g16 + 16 * w;
+        const int sl = uu / NIT, it = uu - sl * NIT;
+        int pix = (uu < SB * NIT) ? pass * SB + sl : kTP;
+        const bool pact = pix < kTP;
+        pix = pact ? pix : 0;
+        int py, px;
+        fpix(pix, py, px);
+        const bool pvalid = pact && (ty0 + py < H) && (tx0 + px < W);
+        const int q = it * 16 + idx;
+        const int yy = s_y0[pix] - R + q / N2, xx = s_x0[pix] - R + q % N2;
+        const bool qok = pvalid && (q < Q) && (yy >= 0) && (yy < H) && (xx >= 0) && (xx < W);
+        pixw[w] = pvalid ? pix : -1;
+        qw[w] = q;
+        rowidx[w] = qok ? kTP + sl * QP + q : ZROW;
+        sacc[w] = 0.f;
+      }
+#pragma unroll
+      for (int l = 0; l < SNL; ++l) {
+        const int slot = l * 256 + tid;
+        const int row = slot >> 2;
+        const int kk = (slot & 3) ^ ((row >> 2) & 1);
+        int y = ty0, x = tx0, pitch = p.f0_pitch;
+        const T* base = f0;
+        y = min(y, H - 1);
+        x = min(x, W - 1);
+        if (row < kTP) {
+          int py, px;
+          fpix(row, py, px);
+          y = min(ty0 + py, H - 1);
+          x = min(tx0 + px, W - 1);
+        } else if (row < used_rows) {
+          const int rr = row - kTP;
+          const int sl = rr / QP, q = rr - sl * QP;
+          const int pix = pass * SB + sl;
+          if (q < Q) {
+            y = min(max(s_y0[pix] - R + q / N2, 0), H - 1);
+            x = min(max(s_x0[pix] - R + q % N2, 0), W - 1);
+            base = f1;
+            pitch = p.f1_pitch;
+          }
+        }
+        ssrc[l] = base + ((size_t)y * W + x) * pitch + kk * E16;
+      }
+    }
+    for (int c0 = 0; c0 < p.C; c0 += CC) {
+      if (active) {
+#pragma unroll
+        for (int l = 0; l < SNL; ++l)
+          if (l * 64 < used_rows) dma16(ssrc[l] + c0, lds0 + (uint32_t)(l * 256 + wave * 64) * 16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __syncthreads();
+      if (active) {
+#pragma unroll
+        for (int w = 0; w < UB; ++w) {
+          const int prow = pixw[w] < 0 ? 0 : pixw[w];
+          const int r0 = rowidx[w];
+          float s = sacc[w];
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) s = dot16<T>(rows[swzr(prow, kk)], rows[swzr(r0, kk)], s);
+          sacc[w] = s;
+        }
+      }
+      __syncthreads();
+    }
+    if (active) {
+#pragma unroll
+      for (int w = 0; w < UB; ++w)
+        if (qw[w] < Q && pixw[w] >= 0) s_D[pixw[w] * (Q + 1) + qw[w]] = sacc[w] * p.scale;
+    }
+  }
+  __syncthreads();
+  if (active) {
+    for (int e = tid; e < kTP * K; e += 256) {
+      int row, kk;
+      if (p.out_nhwc) { row = e / K; kk = e - row * K; } else { kk = e / kTP; row = e - kk * kTP; }
+      int py, px;
+      fpix(row, py, px);
+      const int y = ty0 + py, x = tx0 + px;
+      if (y >= H || x >= W) continue;
+      const int iy = kk / N1, ix = kk - iy * N1;
+      const float ax = s_ax[row], ay = s_ay[row];
+      const float* d = s_D + row * (Q + 1) + iy * N2 + ix;
+      const float top = d[0] + ax * (d[1] - d[0]);
+      const float bot = d[N2] + ax * (d[N2 + 1] - d[N2]);
+      const size_t o = p.out_nhwc ? (((size_t)b * H + y) * W + x) * p.out_pitch + kk : (((size_t)b * p.out_pitch + kk) * H + y) * W + x;
+      out[o] = from_f32<T>(top + ay * (bot - top));
+    }
+  }
+  __syncthreads();
+}
+
+// one LDS-DMA wave-instruction without the M0 save / restore of lc::dma16_so: nothing else in this kernel uses M0
+__device__ __forceinline__ void dma_row(const void* sbase, uint32_t voff, uint32_t lds_wave_base) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_wave_base) : "memory");
+}
+template <int N> __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
+
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+
+template <typename T, int R, int NCB, int NW>
+__global__ __launch_bounds__(64 * NW) void local_corr_rows_kernel(LCTileParams p) {
+  using G = RowsGeom<R, NW>;
+  constexpr int N1 = G::N1, K = G::K, TH = 2 * NW, NIW = G::NIW, NPIX = G::NPIX, SLOTB = G::SLOTB, BWMAX = G::BWMAX;
+  constexpr int NS = G::NS, PF = G::PF, PPB = G::PPB;
+  constexpr int UNR = NS * NCB;                                  // stages per unrolled block: slot and channel block are compile-time
+  constexpr int BIG = 0x3fffffff;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* ot_all = smem + G::REGA;
+  int* s_x0 = reinterpret_cast<int*>(ot_all + G::REGB);          // [NPIX], index = group * 16 + pixel of the group
+  int* s_y0 = s_x0 + NPIX;
+  float* s_ax = reinterpret_cast<float*>(s_y0 + NPIX);
+  float* s_ay = s_ax + NPIX;
+  int* s_gbox = reinterpret_cast<int*>(s_ay + NPIX);             // [NW][8]: gx0, gx1, ga0, ga1, ok, empty
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n16 = lane & 15, kg = lane >> 4;
+  const int H = p.H, W = p.W;
+  const int tiles_per_img = p.tiles_x * p.tiles_y;
+  const int wid = xcd_remap(blockIdx.x, gridDim.x);
+  const int b = wid / tiles_per_img;
+  const int t = wid - b * tiles_per_img;
+  const int ty0 = (t / p.tiles_x) * TH, tx0 = (t % p.tiles_x) * kTW;
+  const T* f0 = static_cast<const T*>(p.f0) + (size_t)b * H * W * p.f0_pitch;
+  const T* f1 = static_cast<const T*>(p.f1) + (size_t)((b + p.f1_shift) % p.B) * H * W * p.f1_pitch;
+  T* out = static_cast<T*>(p.out);
+  const uint32_t lds0 = (uint32_t)(size_t)(lds_u8*)smem;
+
+  const int g = wave, gxi = g & 1, gyi = g >> 1;
+  const int gpy = ty0 + gyi * 4, gpx = tx0 + gxi * 4;            // first pixel of this wave's 4x4 group
+  const int y = gpy + (n16 >> 2), x = gpx + (n16 & 3);
+  const bool pvalid = y < H && x < W;
+
+  // ---- A operand: pixel n16 of the group, channels [64 kg, 64 kg + 64) of every 256-channel block, straight into registers ----
+  u32x4 a[NCB * 8];
+  {
+    const T* pa = f0 + ((size_t)min(y, H - 1) * W + min(x, W - 1)) * p.f0_pitch + kg * 64;
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int s = 0; s < 8; ++s) a[cb * 8 + s] = *reinterpret_cast<const u32x4*>(pa + cb * 256 + s * 8);
+  }
+  // the group's output image starts at zero (what no window position reaches stays zero)
+  {
+    u32x4* ot4 = reinterpret_cast<u32x4*>(ot_all + g * G::OTB);
+    for (int i = lane; i < G::OTB / 16; i += 64) ot4[i] = u32x4{0, 0, 0, 0};
+  }
+  // ---- targets of the group's 16 pixels (replicated over the four lane quarters), group box by shuffles ----
+  int x0 = 0, y0 = 0;
+  float ax = 0.f, ay = 0.f;
+  int lox = BIG, loy = BIG, hix = -BIG, hiy = -BIG;
+  if (pvalid) {
+    float fx, fy;
+    if (p.flow) {
+      fx = p.flow[((size_t)(b * 2 + 0) * H + y) * W + x];
+      fy = p.flow[((size_t)(b * 2 + 1) * H + y) * W + x];
+    } else {
+      fx = -1.f + (2.f * x + 1.f) / W;
+      fy = -1.f + (2.f * y + 1.f) / H;
+    }
+    flow_target(fx, fy, H, W, x0, y0, ax, ay);
+    // a window that meets the image contributes its UNCLIPPED extent (the box is clipped below, keeping one virtual column / row)
+    if (max(x0 - R, 0) <= min(x0 + R + 1, W - 1) && max(y0 - R, 0) <= min(y0 + R + 1, H - 1)) {
+      lox = x0 - R; hix = x0 + R + 1; loy = y0 - R; hiy = y0 + R + 1;
+    }
+  }
+  // every global load of the prologue has landed; said with the builtin so that hipcc KNOWS its vmcnt scoreboard is empty and puts
+  // no wait of its own into the stage loop (it cannot count the asm LDS-DMAs: a vmcnt(0) it placed in front of an MFMA that reads
+  // `a` drained the ring every stage)
+  __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0), expcnt / lgkmcnt untouched
+  if (kg == 0) { s_x0[g * 16 + n16] = x0; s_y0[g * 16 + n16] = y0; s_ax[g * 16 + n16] = ax; s_ay[g * 16 + n16] = ay; }
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) {
+    lox = min(lox, __shfl_xor(lox, o, 64)); loy = min(loy, __shfl_xor(loy, o, 64));
+    hix = max(hix, __shfl_xor(hix, o, 64)); hiy = max(hiy, __shfl_xor(hiy, o, 64));
+  }
+  const bool gempty = __builtin_amdgcn_readfirstlane((int)(hix < lox));
+  // columns: [max(lox, -1), min(hix, W-1)] (column -1 is virtual: staged from a clamped address, zeroed by the mask);
+  // rows: [max(loy, 0), min(hiy, H-1)] are staged; row -1 is the zero start of the previous-row registers, row H one virtual step
+  const int gx0 = __builtin_amdgcn_readfirstlane(gempty ? 0 : max(lox, -1));
+  const int gx1 = __builtin_amdgcn_readfirstlane(gempty ? -1 : min(hix, W - 1));
+  const int ga0 = __builtin_amdgcn_readfirstlane(gempty ? 0 : max(loy, 0));
+  const int ga1 = __builtin_amdgcn_readfirstlane(gempty ? -1 : min(hiy, H - 1));
+  const bool gvirt = __builtin_amdgcn_readfirstlane((int)(!gempty && hiy > H - 1));
+  if (lane == 0) {
+    int* gb = s_gbox + g * 8;
+    gb[0] = gx0; gb[1] = gx1; gb[2] = ga0; gb[3] = ga1;
+    gb[4] = gempty || gx1 - gx0 + 1 <= 16;
+    gb[5] = gempty;
+  }
+  __syncthreads();
+  int bx0 = BIG, bx1 = -BIG, ba0 = BIG, ba1 = -BIG;
+  bool ok = true;
+#pragma unroll
+  for (int gg = 0; gg < NW; ++gg) {
+    const int* gb = s_gbox + gg * 8;
+    if (!gb[5]) { bx0 = min(bx0, gb[0]); bx1 = max(bx1, gb[1]); ba0 = min(ba0, gb[2]); ba1 = max(ba1, gb[3]); }
+    ok = ok && gb[4];
+  }
+  const bool tempty = bx1 < bx0;
+  bx0 = __builtin_amdgcn_readfirstlane(tempty ? 0 : bx0);
+  ba0 = __builtin_amdgcn_readfirstlane(tempty ? 0 : ba0);
+  const int bw = __builtin_amdgcn_readfirstlane(tempty ? 0 : bx1 - bx0 + 1);
+  const int nrows = __builtin_amdgcn_readfirstlane(tempty ? 0 : max(ba1 - ba0 + 1, 0));
+  ok = ok && bw <= BWMAX && nrows <= G::MAXROWS;
+
+  if (!__builtin_amdgcn_readfirstlane((int)ok)) {
+    // =========================== incoherent tile: per-pixel patches, one 8x8 sub-tile after the other ===========================
+#pragma unroll 1
+    for (int sub = 0; sub < NW / 4; ++sub)
+      slow_subtile<T, R>(p, smem, smem + G::SROWB, s_x0 + sub * 64, s_y0 + sub * 64, s_ax + sub * 64, s_ay + sub * 64, tid & 255, wave & 3, lane,
+                         wave < 4, b, ty0 + sub * 8, tx0, f0, f1, out);
+    return;
+  }
+
+  // =========================== streaming path ===========================
+  const int nst = nrows * NCB;
+  // DMA plan: wave-instruction ii = k NW + wave of a stage covers LDS bytes [1024 ii, 1024 ii + 1024) = pixels 2 ii, 2 ii + 1
+  uint32_t voff[NIW];
+  const int ni = (bw + 1) >> 1;
+  const int n_w = __builtin_amdgcn_readfirstlane(ni > wave ? (ni - wave + NW - 1) / NW : 0);
+#pragma unroll
+  for (int k = 0; k < NIW; ++k) {
+    const int P = (k * NW + wave) * 64 + lane;
+    const int pxb = P >> 5, qp = P & 31;
+    const int q = (qp & 24) | ((qp ^ pxb) & 7);                  // the slot holds channel piece q of its 256-channel block
+    const int xs = min(max(bx0 + min(pxb, max(bw - 1, 0)), 0), W - 1);
+    voff[k] = (uint32_t)(xs * p.f1_pitch + q * 8) * 2u;
+  }
+  // B fragment addresses: lane (n16, kg) reads piece s of quarter kg of staged pixel col0 + n16
+  uint32_t bo[8];
+  {
+    const int pxb = min(max(gx0 - bx0 + n16, 0), BWMAX - 1);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) bo[s] = lds0 + (uint32_t)(pxb * 512 + kg * 128 + ((s ^ (pxb & 7)) << 4));
+  }
+  // per accumulator row r4 (pixel 4 kg + r4 of the group): blend weights (the C^-1/2 scale folded into the y weights), the LDS
+  // address of row 0 of the image column this lane produces for that pixel, and (in bytes of image rows) where its window starts
+  float axv[4], ay0[4], ay1[4];
+  uint32_t wbase[4];
+  int wyb[4];
+  constexpr int ROWB = N1 * 2;                                   // bytes per image row
+  const uint32_t otb = lds0 + (uint32_t)(G::REGA + g * G::OTB);
+#pragma unroll
+  for (int r4 = 0; r4 < 4; ++r4) {
+    const int pp = 4 * kg + r4, r = g * 16 + pp;
+    axv[r4] = s_ax[r];
+    const float ayp = s_ay[r];
+    ay1[r4] = ayp * p.scale;
+    ay0[r4] = p.scale - ay1[r4];
+    const int ix = gx0 + n16 - (s_x0[r] - R);                    // window column this lane produces for that pixel
+    const bool colvalid = (unsigned)ix < (unsigned)N1;
+    wbase[r4] = otb + (uint32_t)(colvalid ? pp * PPB + ix * 2 : 16 * PPB);
+    wyb[r4] = (s_y0[r] - R - ba0) * ROWB;                        // box row ya = ba0 + j is image row j - wyb / ROWB (window row + 1)
+  }
+  const int xa = gx0 + n16;
+  const bool dvalid = xa >= 0 && xa <= W - 1;
+  const bool inner = __builtin_amdgcn_readfirstlane((int)(gx0 >= 0 && gx0 + 15 <= W - 1));
+  const int gs0 = ga0 - ba0, gs1 = ga1 - ba0;
+  float tprev[4] = {0.f, 0.f, 0.f, 0.f};
+  float4_t acc = {0.f, 0.f, 0.f, 0.f};
+
+  // box row ya = ba0 + j, jb = j ROWB: x-blend (DPP shift), y-blend against the previous row, store at the clamped image row
+  auto emit_row = [&](const float4_t& d4, int jb) {
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      float d = d4[r4];
+      if (!inner) d = dvalid ? d : 0.f;
+      const float tc = d + axv[r4] * (right_neighbour(d) - d);
+      const float v = ay0[r4] * tprev[r4] + ay1[r4] * tc;
+      tprev[r4] = tc;
+      const int rowb = min(max(jb - wyb[r4], 0), (N1 + 1) * ROWB);
+      *reinterpret_cast<__attribute__((address_space(3))) T*>((lds_u8*)(size_t)(wbase[r4] + (uint32_t)rowb)) = from_f32<T>(v);
+    }
+  };
+
+  auto run = [&](auto nwi_c) {
+    constexpr int NWI = decltype(nwi_c)::value;
+    const T* rb = f1 + (size_t)ba0 * W * p.f1_pitch;             // next stage to issue: row pointer (channel block 0)
+    const size_t rstride = (size_t)W * p.f1_pitch;
+    const uint32_t dst0 = lds0 + (uint32_t)(wave * 1024);
+    auto issue = [&](auto slot_c, auto cb_c) {
+      constexpr int SLOT = decltype(slot_c)::value, CB = decltype(cb_c)::value;
+#pragma unroll
+      for (int k = 0; k < NWI; ++k) dma_row(rb + CB * 256, voff[k], dst0 + (uint32_t)(SLOT * SLOTB + k * NW * 1024));
+      if (CB == NCB - 1) rb += rstride;
+    };
+    // fill: the first PF stages
+    if (PF >= 1 && nst > 0) issue(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    if (PF >= 2 && nst > 1) issue(std::integral_constant<int, 1 % NS>{}, std::integral_constant<int, 1 % NCB>{});
+    for (int st0 = 0; st0 < nst; st0 += UNR) {
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int st = st0 + u;
+        if (st < nst) {
+          if (st + PF < nst) {
+            if (u == 0) issue(std::integral_constant<int, (0 + PF) % NS>{}, std::integral_constant<int, (0 + PF) % NCB>{});
+            if (u == 1) issue(std::integral_constant<int, (1 + PF) % NS>{}, std::integral_constant<int, (1 + PF) % NCB>{});
+            if (u == 2) issue(std::integral_constant<int, (2 + PF) % NS>{}, std::integral_constant<int, (2 + PF) % NCB>{});
+            if (u == 3) issue(std::integral_constant<int, (3 + PF) % NS>{}, std::integral_constant<int, (3 + PF) % NCB>{});
+            if (u == 4) issue(std::integral_constant<int, (4 + PF) % NS>{}, std::integral_constant<int, (4 + PF) % NCB>{});
+            if (u == 5) issue(std::integral_constant<int, (5 + PF) % NS>{}, std::integral_constant<int, (5 + PF) % NCB>{});
+            if (u == 6) issue(std::integral_constant<int, (6 + PF) % NS>{}, std::integral_constant<int, (6 + PF) % NCB>{});
+            if (u == 7) issue(std::integral_constant<int, (7 + PF) % NS>{}, std::integral_constant<int, (7 + PF) % NCB>{});
+            vm_wait<PF * NWI>();
+          } else if (PF >= 2 && st + 1 < nst) {
+            vm_wait<(PF - 1) * NWI>();
+          } else {
+            vm_wait<0>();
+          }
+          raw_barrier();
+          const int cb = u % NCB;
+          const int jr = NCB == 1 ? st : st >> 1;
+          if (jr >= gs0 && jr <= gs1) {
+            if (cb == 0) acc = float4_t{0.f, 0.f, 0.f, 0.f};
+            u32x4 bq[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+              bq[s] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>((lds_u8*)(size_t)(bo[s]) + (u % NS) * SLOTB);
+            __builtin_amdgcn_sched_barrier(0);                   // all eight reads in flight before the first MFMA waits
+#pragma unroll
+            for (int s = 0; s < 8; ++s) acc = mfma16r(a[cb * 8 + s], bq[s], acc, T{});
+            if (cb == NCB - 1) {
+              emit_row(acc, jr * ROWB);
+            }
+          }
+        }
+      }
+    }
+  };
+  switch (n_w) {
+    case 0: run(std::integral_constant<int, 0>{}); break;
+    case 1: run(std::integral_constant<int, 1>{}); break;
+    case 2: if constexpr (NIW >= 2) run(std::integral_constant<int, 2>{}); break;
+    default: if constexpr (NIW >= 3) run(std::integral_constant<int, 3>{}); break;
+  }
+  if (gvirt) emit_row(float4_t{0.f, 0.f, 0.f, 0.f}, (H - ba0) * ROWB);   // the virtual row below the image
+
+  // ---- write the group's output image: wave-private, no barrier ----
+  const T* ot = reinterpret_cast<const T*>(ot_all + g * G::OTB);
+  for (int e = lane; e < 16 * K; e += 64) {
+    int m, kk;
+    if (p.out_nhwc) { m = e / K; kk = e - m * K; } else { kk = e >> 4; m = e & 15; }
+    const int oy = gpy + (m >> 2), ox = gpx + (m & 3);
+    if (oy >= H || ox >= W) continue;
+    const size_t o = p.out_nhwc ? (((size_t)b * H + oy) * W + ox) * p.out_pitch + kk : (((size_t)b * p.out_pitch + kk) * H + oy) * W + ox;
+    out[o] = ot[m * (PPB / 2) + N1 + kk];
+  }
+}
+
+template <typename T, int R, int NCB, int NW>
+int launch_rows(LCTileParams p, hipStream_t stream) {
+  using G = RowsGeom<R, NW>;
+  constexpr size_t smem = G::SMEM;
+  static std::atomic<uint64_t> attr_done{0};
+  if (int rc = ensure_dyn_smem(reinterpret_cast<const void*>(local_corr_rows_kernel<T, R, NCB, NW>), (int)smem, attr_done, "roma_local_corr")) return rc;
+  p.tiles_x = (p.W + kTW - 1) / kTW;
+  p.tiles_y = (p.H + 2 * NW - 1) / (2 * NW);
+  const int grid = p.B * p.tiles_x * p.tiles_y;
+  hipLaunchKernelGGL((local_corr_rows_kernel<T, R, NCB, NW>), dim3(grid), dim3(64 * NW), smem, stream, p);
+  ROMA_CHECK_LAUNCH();
+}
+
+template <typename T, int R>
+int launch_rows_c(const LCTileParams& p, int tile_h, hipStream_t stream) {
+  if (p.C == 256) return tile_h == 16 ? launch_rows<T, R, 1, 8>(p, stream) : launch_rows<T, R, 1, 4>(p, stream);
+  if (p.C == 512) return tile_h == 16 ? launch_rows<T, R, 2, 8>(p, stream) : launch_rows<T, R, 2, 4>(p, stream);
+  set_error("local_corr_rows: C = %d (supported: 256, 512)", p.C);
+  return ROMA_E_UNSUPPORTED;
+}
+
+}  // namespace
+
+bool local_corr_rows_supports(int C) { return C == 256 || C == 512; }
+
+int local_corr_rows(const LCTileParams& p, int r, int dtype, int tile_h, hipStream_t stream) {
+  if (dtype == ROMA_F16) {
+    switch (r) {
+      case 1: return launch_rows_c<half_t, 1>(p, tile_h, stream);
+      case 2: return launch_rows_c<half_t, 2>(p, tile_h, stream);
+      case 3: return launch_rows_c<half_t, 3>(p, tile_h, stream);
+    }
+  } else if (dtype == ROMA_BF16) {
+    switch (r) {
+      case 1: return launch_rows_c<bf16_t, 1>(p, tile_h, stream);
+      case 2: return launch_rows_c<bf16_t, 2>(p, tile_h, stream);
+      case 3: return launch_rows_c<bf16_t, 3>(p, tile_h, stream);
+    }
+  }
+  set_error("local_corr_rows: unsupported r=%d dtype=%d", r, dtype);
+  return ROMA_E_UNSUPPORTED;
+}
+
+}  // namespace roma

@@ -5,16 +5,15 @@
 //   * the 8x4-tile kernel of local_corr.hip is bound by per-tile FIXED costs (flow -> box round trips, plan, ~16 barriers), hidden
 //     only by 4-5 co-resident workgroups; a 64-pixel tile halves those costs per pixel and stages 3.9 + 1 instead of 5.2 + 1 rows
 //     per pixel;
-//   * the persistent loader / consumer ring (local_corr_ring.hip) removed the DMA wait but has ONE workgroup per CU, so nothing
+//   * the persistent loader / consumer ring (local_corr_ring.hip, removed in round 3) removed the DMA wait but has ONE workgroup per CU, so nothing
 //     overlaps its bookkeeping: slower.  Its consumer half is what pays: wave g = 4x4 group g, all B fragments read up front,
 //     back-to-back MFMAs, and the 4-tap blend in registers (DPP shift for the right-hand tap, the next accumulator block for the
 //     lower one) instead of a zero-initialised (2r+2)^2 image per pixel.
 // This kernel is that consumer half inside the one-tile-per-workgroup skeleton (3-4 workgroups per CU for latency hiding).
 // Tiles whose targets are not compact take per-pixel patches on the VALU (same staging), like the other kernels.
-#include <cstdlib>
 #include "common.h"
 #include "lc_device.h"
-#include "local_corr_ring.h"
+#include "lc_variants.h"
 
 namespace roma {
 namespace {
@@ -29,7 +28,7 @@ template <int R> struct T8Geom {
 };
 
 template <typename T, int R>
-__global__ __launch_bounds__(256, R <= 2 ? 4 : 3) void local_corr_t8_kernel(LCRingParams p) {
+__global__ __launch_bounds__(256, R <= 2 ? 4 : 3) void local_corr_t8_kernel(LCTileParams p) {
   using G = T8Geom<R>;
   constexpr int N1 = 2 * R + 1, N2 = G::N2, Q = N2 * N2, K = N1 * N1;
   constexpr int MAXR = G::MAXR, GHMAX = G::GHMAX, NB = GHMAX;
@@ -399,7 +398,7 @@ template <int R> constexpr size_t t8_smem_bytes() {
 }
 
 template <typename T, int R>
-int launch_t8(LCRingParams p, hipStream_t stream) {
+int launch_t8(LCTileParams p, hipStream_t stream) {
   constexpr size_t smem = t8_smem_bytes<R>();
   static std::atomic<uint64_t> attr_done{0};
   if (int rc = ensure_dyn_smem(reinterpret_cast<const void*>(local_corr_t8_kernel<T, R>), (int)smem, attr_done, "roma_local_corr")) return rc;
@@ -413,7 +412,7 @@ int launch_t8(LCRingParams p, hipStream_t stream) {
 }  // namespace
 
 // entry used by roma_local_corr (local_corr.hip) for 16-bit channels-last inputs with r <= 3 and C a multiple of 32
-int local_corr_t8(const LCRingParams& p, int r, int dtype, hipStream_t stream) {
+int local_corr_t8(const LCTileParams& p, int r, int dtype, hipStream_t stream) {
   if (dtype == ROMA_F16) {
     switch (r) {
       case 1: return launch_t8<half_t, 1>(p, stream);

@@ -121,7 +121,7 @@ def test_local_corr_matrix_core_path_vs_fp32_kernel(shape, kind, dtype):
     assert maxerr(out, ref) <= tol
 
 
-@pytest.mark.parametrize("variant", ["tile8x4", "tile8x8", "ring"])
+@pytest.mark.parametrize("variant", ["tile8x4", "tile8x8", "rows8", "rows16"])
 @pytest.mark.parametrize("shape", [(1, 512, 70, 70, 3), (1, 256, 140, 140, 2), (2, 256, 37, 53, 1), (1, 64, 37, 53, 2), (2, 32, 21, 18, 3)])
 @pytest.mark.parametrize("kind", ["coherent", "adversarial", "mixed"])
 def test_local_corr_kernel_variants_agree(shape, kind, variant):
