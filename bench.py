@@ -175,6 +175,43 @@ def parity_legs(device, dtype, pin, images):
 
 
 LC_SHAPES = [("L16", 512, 40, 7), ("L8", 512, 70, 3), ("L4", 256, 140, 2), ("U8", 512, 108, 3), ("U4", 256, 216, 2)]
+# what roma_local_corr's AUTO policy launches for 16-bit channels-last inputs (roma_amd/csrc/local_corr.hip, launch_any): names as
+# rocprofv3 shows them
+LC_KERNELS = ("local_corr_rows_kernel (row-streaming, r <= 3 and C = 256 / 512: the scale-8 and scale-4 levels), local_corr_mfma_kernel "
+              "(8x4-pixel tiles, 32-channel chunks: the r = 7 scale-16 level)")
+
+
+def known_warp_flow(scale_unused, b, h, w, device, upsample_unused, rot_deg=8.0, scale=1.08, shift=0.04, jitter_px=0.5, gen=None):
+    """The flow a converged matcher would predict on roma_amd.synthetic.synthetic_pair: B(p) = A(theta p), so the B -> A half of the
+    symmetric batch is theta applied to the pixel grid and the A -> B half its inverse; + N(0, (0.5 px)^2) as in SURVEY §8(d)."""
+    import math
+    import torch
+    c, s_ = math.cos(math.radians(rot_deg)) * scale, math.sin(math.radians(rot_deg)) * scale
+    th = torch.tensor([[c, -s_, shift], [s_, c, -shift], [0.0, 0.0, 1.0]], dtype=torch.float64)
+    inv = torch.linalg.inv(th)
+    xs = torch.linspace(-1 + 1 / w, 1 - 1 / w, w, dtype=torch.float64)
+    ys = torch.linspace(-1 + 1 / h, 1 - 1 / h, h, dtype=torch.float64)
+    gx, gy = xs[None, :].expand(h, w), ys[:, None].expand(h, w)
+
+    def apply(m):
+        return torch.stack((m[0, 0] * gx + m[0, 1] * gy + m[0, 2], m[1, 0] * gx + m[1, 1] * gy + m[1, 2]))
+    half = b // 2
+    flow = torch.cat((apply(inv)[None].expand(half, 2, h, w), apply(th)[None].expand(b - half, 2, h, w))).float()
+    noise = torch.randn(flow.shape, generator=gen)
+    noise[:, 0] *= jitter_px * 2 / w
+    noise[:, 1] *= jitter_px * 2 / h
+    return (flow + noise).contiguous().to(device)
+
+
+def lc_roofline(lc, traffic=None, tnote=None, flow_note=""):
+    from roma_amd import ops
+    a = lc["bytes"] / lc["seconds"]
+    return {"bound": "hbm", "kernel": LC_KERNELS, "achieved": a / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            "frac": a / HBM_PEAK, "traffic": traffic, "traffic_note": tnote, "launches": lc["launches"],
+            "event_bracket_overhead_us": ops.TIMER.bracket_overhead_s * 1e6,
+            "avg_launch_us": lc["seconds"] / lc["launches"] * 1e6, "algorithmic_bytes_per_launch": lc["bytes"] / lc["launches"],
+            "flow": flow_note,
+            "per_shape": {k: {"us": v[2] / v[0] * 1e6, "GB/s": v[1] / v[2] / 1e9} for k, v in sorted(lc["by_tag"].items())}}
 
 
 def local_corr_microbench(device, dtype, pairs, iters=20):
@@ -228,15 +265,15 @@ def local_corr_microbench(device, dtype, pairs, iters=20):
         out[kind] = {"achieved": tot_b / tot_t / 1e9, "frac": tot_b / tot_t / HBM_PEAK, "unit": "GB/s", "B": B, "per_shape": per}
         del f0, f1, o, flow
     out["note"] = ("standalone launches of roma_local_corr on the 5 call shapes (B = 2 x pairs per launch), same process, after the timed "
-                   "region; kernel variant AUTO: 8x8-pixel tiles for launches of >= 2048 tiles (the 16-pair rows), 8x4 tiles otherwise")
+                   "region; kernel variant AUTO: " + LC_KERNELS)
     return out
 
 
-LOCAL_CORR_SOURCES = ("local_corr.hip", "local_corr_t8.hip", "local_corr_ring.hip", "local_corr_ring.h", "lc_device.h")
+LOCAL_CORR_SOURCES = ("local_corr.hip", "local_corr_t8.hip", "local_corr_rows.hip", "lc_variants.h", "lc_device.h", "common.h")
 
 
 def kernel_source_sha1():
-    """One digest over every source file of roma_local_corr (dispatch + the three kernels + their shared device header)."""
+    """One digest over every source file of roma_local_corr (dispatch + the kernels + their shared device headers, common.h included)."""
     h = hashlib.sha1()
     for f in LOCAL_CORR_SOURCES:
         h.update(open(os.path.join(ROOT, "roma_amd", "csrc", f), "rb").read())
@@ -470,15 +507,53 @@ def main():
         else:
             lc = summ.get("local_corr")
             if lc:
-                a = lc["bytes"] / lc["seconds"]
                 traffic, tnote = measured_traffic() if args.workload == "outdoor" and P == 1 else (None, "collected for the default workload only")
-                roof = {"bound": "hbm", "kernel": "local_corr_kernel", "achieved": a / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                        "frac": a / HBM_PEAK, "traffic": traffic, "traffic_note": tnote, "launches": lc["launches"],
-                        "event_bracket_overhead_us": ops.TIMER.bracket_overhead_s * 1e6,
-                        "avg_launch_us": lc["seconds"] / lc["launches"] * 1e6, "algorithmic_bytes_per_launch": lc["bytes"] / lc["launches"],
-                        "flow": "as produced by the timed pipeline (random-init weights => incoherent; see roofline_microbench for the "
-                                "SURVEY §8(d) coherent-flow protocol)",
-                        "per_shape": {k: {"us": v[2] / v[0] * 1e6, "GB/s": v[1] / v[2] / 1e9} for k, v in sorted(lc["by_tag"].items())}}
+                roof = lc_roofline(lc, traffic, tnote, "as produced by the timed pipeline (random-init weights => spatially incoherent flow: every "
+                                   "pixel gathers its own (2r+2)^2 patch; see roofline_pipeline_coherent / roofline_microbench for coherent flow)")
+        coherent = fp32_mode = None
+        if args.workload == "outdoor" and world == 1 and not args.no_microbench and eager is not None:
+            # (1) the SAME pipeline with the flow entering every refiner replaced by the known warp of the synthetic pair + 0.5 px noise
+            # (Decoder.flow_override, diagnostic): the local_corr regime of a trained matcher, inside the pipeline.  Not part of `value`.
+            gen = torch.Generator().manual_seed(0)
+            cache = {}
+
+            def override(ins, b, hs, ws, dev, upsample):
+                key = (ins, b, hs, ws, upsample)
+                if key not in cache:
+                    cache[key] = known_warp_flow(ins, b, hs, ws, dev, upsample, gen=gen)
+                return cache[key]
+            model.decoder.flow_override = override
+            try:
+                eager()
+                torch.cuda.synchronize()
+                n_co = max(2, min(args.steps, 5))
+                ops.TIMER.start()
+                for _ in range(n_co):
+                    eager()
+                torch.cuda.synchronize()
+                ops.TIMER.stop()
+                lcc = ops.TIMER.summary().get("local_corr")
+                if lcc:
+                    coherent = lc_roofline(lcc, None, "not collected", "DIAGNOSTIC: same pipeline, same weights and inputs, but the flow entering "
+                                           "every refiner replaced by the synthetic pair's known similarity warp + N(0, (0.5 px)^2) "
+                                           f"(Decoder.flow_override); {n_co} eager steps after the timed region")
+            finally:
+                model.decoder.flow_override = None
+            # (2) throughput of the mode that meets the 1e-3 parity bar (fp32 storage and arithmetic, product GP kernels): same step
+            m32 = build_model(device, torch.float32)
+            A_lo, B_lo, A_hi, B_hi = resident
+            m32.match_tensors(A_lo, B_lo, A_hi, B_hi)
+            torch.cuda.synchronize()
+            n32 = max(2, min(args.steps, 5))
+            t1 = time.perf_counter()
+            for _ in range(n32):
+                m32.match_tensors(A_lo, B_lo, A_hi, B_hi)
+            torch.cuda.synchronize()
+            dt32 = (time.perf_counter() - t1) / n32
+            fp32_mode = {"value": P / dt32, "unit": "image-pairs/s", "ms_per_step": dt32 * 1e3, "steps": n32,
+                         "note": "fp32 mode (the one whose (warp, certainty) meet the 1e-3 max-abs bar: see `parity`), same workload and inputs"}
+            del m32
+            torch.cuda.empty_cache()
         micro = None
         if not args.no_microbench and args.workload == "outdoor":
             micro = local_corr_microbench(device, dtype, P)
@@ -518,7 +593,8 @@ def main():
             "n_gpus": n_distinct if rehearsal else world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {torch.float16: "fp16", torch.bfloat16: "bf16", torch.float32: "fp32"}[dtype],
             "data": "synthetic", "config": cfg,
-            "roofline": roof, "roofline_microbench": micro, "cpu_baseline": cpu, "parity": parity, "parity_fp16": parity16,
+            "roofline": roof, "roofline_pipeline_coherent": coherent, "roofline_microbench": micro, "value_fp32_mode": fp32_mode,
+            "cpu_baseline": cpu, "parity": parity, "parity_fp16": parity16,
         }
         if rehearsal:
             line["rehearsal"] = True

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ROMA_ABI_VERSION 2
+#define ROMA_ABI_VERSION 3
 
 enum { ROMA_F32 = 0, ROMA_F16 = 1, ROMA_BF16 = 2 };
 enum { ROMA_NCHW = 0, ROMA_NHWC = 1 };
@@ -98,8 +98,8 @@ int roma_cos_kernel(const void* x, const void* y, float* K, int B, int N, int M,
  * strideA; only its lower triangle is read) is replaced by its Cholesky factor L (lower), and W (nb x nb, ldw, strideW)
  * receives L^-1.  A non-positive or NaN pivot p (0-based, within the block) is clamped and recorded: if info[b] == 0 it
  * becomes info_base + p + 1, so a zero-initialised info keeps the FIRST failing pivot of a whole blocked solve (the
- * reference's torch.linalg.inv raises in that case, matcher.py:261).  nb <= 64.  The panel and substitution steps around it
- * are plain GEMMs done by the caller (roma_amd/ops.py: spd_solve). */
+ * reference's torch.linalg.inv raises in that case, matcher.py:261).  nb <= 64.  spd_solve (roma_amd/ops.py) calls it once, for the
+ * first block; every later diagonal block is factored inside roma_chol_step, and the substitutions are roma_chol_subst_step. */
 int roma_chol_diag_block(float* A, int lda, long strideA, float* W, int ldw, long strideW, int nb, int B, int* info,
                          int info_base, void* stream);
 
@@ -157,11 +157,13 @@ int roma_kde_density(const float* x, float* density, int N, int down, float std,
  * torch.multinomial(..., replacement=False) draws:  w_i = (thresh >= 0 && p_i > thresh) ? 1 : p_i  (the "threshold" sample
  * mode, matcher.py:474-477);  key_i = w_i / E_i with E_i = -ln(u_i) i.i.d. Exp(1); the k largest keys are a draw of k items
  * without replacement with probabilities proportional to w (what multinomial does internally).  u_i comes from a counter
- * hash of (seed, c_i) — u = ((fmix32(c_i * 0x9E3779B1 + seed * 0x85EBCA77 + 0x165667B1) >> 8) + 0.5) / 2^24, fmix32 = the
- * MurmurHash3 finaliser — so a CPU oracle reproduces the draw.  c_i = counter[i] (int64, e.g. the item's index in the
+ * hash of (seed, stage, c_i) — u = ((fmix32(fmix32(seed ^ stage * 0x9E3779B9) + c_i * 0x9E3779B1) >> 8) + 0.5) / 2^24, fmix32 = the
+ * MurmurHash3 finaliser — so a CPU oracle reproduces the draw.  `stage` separates the draws of one sample() call (0 = the
+ * certainty draw, 1 = the balanced draw): mixed non-linearly, so no (seed, stage) stream is a shifted copy of another.  c_i = counter[i] (int64, e.g. the item's index in the
  * population the first draw came from: the second draw then does not depend on the ORDER of the first) or i when counter
  * is NULL.  p, keys: (N) fp32; w_i <= 0 (or NaN) gives key 0. */
-int roma_race_keys(const float* p, const long* counter, float* keys, long N, float thresh, unsigned seed, void* stream);
+int roma_race_keys(const float* p, const long* counter, float* keys, long N, float thresh, unsigned seed, unsigned stage,
+                   void* stream);
 
 /* Nearest neighbours for RegressionMatcher.match_keypoints (matcher.py:576-591): idx[i] = arg min_j |q_i - r_j|^2 over 2-D points
  * (lowest j on exact ties).  The reference materialises cdist(x_A_to_B, x_B) and compares it with its row / column minima;

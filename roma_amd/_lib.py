@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libroma_hip.so")
 ROMA_F32, ROMA_F16, ROMA_BF16 = 0, 1, 2
 ROMA_NCHW, ROMA_NHWC = 0, 1
 LC_VARIANTS = {"auto": 0, "tile8x4": 1, "tile8x8": 2, "rows8": 3, "rows16": 4}
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # name -> argtypes; restype is c_int unless listed in _RESTYPES.  Mirrors include/roma_hip.h one to one.
 SIGNATURES = {
@@ -38,7 +38,7 @@ SIGNATURES = {
     "roma_match_finalize": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "roma_kde_density": [c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p],
     "roma_nn_argmin": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
-    "roma_race_keys": [c_void_p, c_void_p, c_void_p, c_long, c_float, ctypes.c_uint, c_void_p],
+    "roma_race_keys": [c_void_p, c_void_p, c_void_p, c_long, c_float, ctypes.c_uint, ctypes.c_uint, c_void_p],
     "roma_dwconv5x5_bn_relu": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "roma_resample_u8": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p],
     "roma_normalize_u8": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p],

@@ -459,6 +459,8 @@ extern "C" int roma_chol_step(float* A, int lda, long strideA, int n, int ncols,
                               float* R, int ldr, long strideR, float* Wn, int ldwn, long strideWn, int* info, int info_base, int B,
                               void* stream) {
   ROMA_REQUIRE(A && W && R && info, ROMA_E_ARG, "roma_chol_step: null pointer");
+  ROMA_REQUIRE(nb == NBMAX || j + nb >= n, ROMA_E_UNSUPPORTED, "roma_chol_step: block size %d with blocks to follow (the next diagonal block is "
+               "factored at %d rows: only the last block may be narrower)", nb, NBMAX);
   ROMA_REQUIRE(nb >= 1 && nb <= NBMAX && B >= 1 && n >= 1 && ncols >= n && j >= 0 && j + nb <= n && lda >= ncols && ldw >= nb &&
                    ldr >= ncols - (j + nb) && (Wn == nullptr || ldwn >= 1),
                ROMA_E_SHAPE, "roma_chol_step: bad shape n=%d ncols=%d j=%d nb=%d B=%d", n, ncols, j, nb, B);

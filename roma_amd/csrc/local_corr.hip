@@ -910,12 +910,15 @@ int launch_any(const LCParams& p, hipStream_t s) {
       //   8x8 tiles, 32-channel chunks (local_corr_t8.hip): half the fixed cost per pixel, register epilogue;
       //   row streaming, 8x8 or 8x16 tiles (local_corr_rows.hip, C = 256 / 512): whole 512-byte pixel rows through a 4-slot LDS
       //     ring, f0 in registers.
+      // AUTO: the row-streaming kernel wherever it applies (coherent flow, the regime of a trained matcher: 26.6 vs 20.9 % of 8 TB/s at
+      // one pair per launch, 42.4 vs 35.2 % at 16 pairs; on fully incoherent flow its patch path runs at 3 workgroups per CU and is
+      // ~20 % behind the 8x4-tile kernel's: gpurun_out/r3_lcb5*.txt); otherwise by launch size as before.
       const int nt8 = p.B * ((p.H + 7) / 8) * ((p.W + 7) / 8);
-      int v = p.variant;
-      if (v == ROMA_LC_AUTO) v = (p.C % 32 == 0 && nt8 >= 2048) ? ROMA_LC_TILE8X8 : ROMA_LC_TILE8X4;
       // the tile kernels address one feature map with 32-bit byte offsets
       const bool t8_ok = p.C % 32 == 0 && (size_t)p.H * p.W * (size_t)(p.f0_pitch > p.f1_pitch ? p.f0_pitch : p.f1_pitch) * 2 < (1ull << 32);
-      const bool rows_ok = t8_ok && local_corr_rows_supports(p.C);
+      const bool rows_ok = t8_ok && local_corr_rows_supports(p.C) && nt8 < (1 << 21);
+      int v = p.variant;
+      if (v == ROMA_LC_AUTO) v = rows_ok ? ROMA_LC_ROWS8 : (p.C % 32 == 0 && nt8 >= 2048) ? ROMA_LC_TILE8X8 : ROMA_LC_TILE8X4;
       if ((v == ROMA_LC_ROWS8 || v == ROMA_LC_ROWS16) && !rows_ok) v = ROMA_LC_TILE8X8;
       if (v == ROMA_LC_TILE8X8 && !t8_ok) v = ROMA_LC_TILE8X4;
       if (v != ROMA_LC_TILE8X4) {

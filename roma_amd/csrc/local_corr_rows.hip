@@ -202,6 +202,16 @@ template <int N> __device__ __forceinline__ void vm_wait() { asm volatile("s_wai
 
 typedef __attribute__((address_space(3))) unsigned char lds_u8;
 
+// min / max over each row of 16 lanes, result in every lane: four DPP steps on the VALU (quad xor 1, quad xor 2, half-row mirror, row
+// mirror) instead of four ds_bpermute round trips through the LDS pipe
+template <int CTRL> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+__device__ __forceinline__ int row16_min(int v) {
+  v = min(v, dpp_i<0xB1>(v)); v = min(v, dpp_i<0x4E>(v)); v = min(v, dpp_i<0x141>(v)); return min(v, dpp_i<0x140>(v));
+}
+__device__ __forceinline__ int row16_max(int v) {
+  v = max(v, dpp_i<0xB1>(v)); v = max(v, dpp_i<0x4E>(v)); v = max(v, dpp_i<0x141>(v)); return max(v, dpp_i<0x140>(v));
+}
+
 template <typename T, int R, int NCB, int NW>
 __global__ __launch_bounds__(64 * NW) void local_corr_rows_kernel(LCTileParams p) {
   using G = RowsGeom<R, NW>;
@@ -222,13 +232,18 @@ __global__ __launch_bounds__(64 * NW) void local_corr_rows_kernel(LCTileParams p
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n16 = lane & 15, kg = lane >> 4;
   const int H = p.H, W = p.W;
+  // block id -> (batch item, tile) by float reciprocals (exact for grids below 2^21 tiles, checked by the host): an integer division
+  // costs ~35 instructions each, and there were four of them per wave
   const int tiles_per_img = p.tiles_x * p.tiles_y;
   const int wid = xcd_remap(blockIdx.x, gridDim.x);
-  const int b = wid / tiles_per_img;
+  const int b = (int)(((float)wid + 0.5f) * p.inv_tiles_per_img);
   const int t = wid - b * tiles_per_img;
-  const int ty0 = (t / p.tiles_x) * TH, tx0 = (t % p.tiles_x) * kTW;
+  const int tyi = (int)(((float)t + 0.5f) * p.inv_tiles_x);
+  const int ty0 = tyi * TH, tx0 = (t - tyi * p.tiles_x) * kTW;
+  int b1 = b + p.f1_shift;
+  b1 -= b1 >= p.B ? p.B : 0;
   const T* f0 = static_cast<const T*>(p.f0) + (size_t)b * H * W * p.f0_pitch;
-  const T* f1 = static_cast<const T*>(p.f1) + (size_t)((b + p.f1_shift) % p.B) * H * W * p.f1_pitch;
+  const T* f1 = static_cast<const T*>(p.f1) + (size_t)b1 * H * W * p.f1_pitch;
   T* out = static_cast<T*>(p.out);
   const uint32_t lds0 = (uint32_t)(size_t)(lds_u8*)smem;
 
@@ -240,7 +255,7 @@ __global__ __launch_bounds__(64 * NW) void local_corr_rows_kernel(LCTileParams p
   // ---- A operand: pixel n16 of the group, channels [64 kg, 64 kg + 64) of every 256-channel block, straight into registers ----
   u32x4 a[NCB * 8];
   {
-    const T* pa = f0 + ((size_t)min(y, H - 1) * W + min(x, W - 1)) * p.f0_pitch + kg * 64;
+    const T* pa = f0 + (uint32_t)((min(y, H - 1) * W + min(x, W - 1)) * p.f0_pitch + kg * 64);   // one map < 4 GB (host check)
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
@@ -258,8 +273,9 @@ __global__ __launch_bounds__(64 * NW) void local_corr_rows_kernel(LCTileParams p
   if (pvalid) {
     float fx, fy;
     if (p.flow) {
-      fx = p.flow[((size_t)(b * 2 + 0) * H + y) * W + x];
-      fy = p.flow[((size_t)(b * 2 + 1) * H + y) * W + x];
+      const float* fb = p.flow + (size_t)b * 2 * H * W;
+      fx = fb[(uint32_t)(y * W + x)];
+      fy = fb[(uint32_t)(H * W + y * W + x)];
     } else {
       fx = -1.f + (2.f * x + 1.f) / W;
       fy = -1.f + (2.f * y + 1.f) / H;
@@ -275,11 +291,7 @@ __global__ __launch_bounds__(64 * NW) void local_corr_rows_kernel(LCTileParams p
   // `a` drained the ring every stage)
   __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0), expcnt / lgkmcnt untouched
   if (kg == 0) { s_x0[g * 16 + n16] = x0; s_y0[g * 16 + n16] = y0; s_ax[g * 16 + n16] = ax; s_ay[g * 16 + n16] = ay; }
-#pragma unroll
-  for (int o = 1; o < 16; o <<= 1) {
-    lox = min(lox, __shfl_xor(lox, o, 64)); loy = min(loy, __shfl_xor(loy, o, 64));
-    hix = max(hix, __shfl_xor(hix, o, 64)); hiy = max(hiy, __shfl_xor(hiy, o, 64));
-  }
+  lox = row16_min(lox); loy = row16_min(loy); hix = row16_max(hix); hiy = row16_max(hiy);
   const bool gempty = __builtin_amdgcn_readfirstlane((int)(hix < lox));
   // columns: [max(lox, -1), min(hix, W-1)] (column -1 is virtual: staged from a clamped address, zeroed by the mask);
   // rows: [max(loy, 0), min(hiy, H-1)] are staged; row -1 is the zero start of the previous-row registers, row H one virtual step
@@ -337,8 +349,9 @@ __global__ __launch_bounds__(64 * NW) void local_corr_rows_kernel(LCTileParams p
   uint32_t bo[8];
   {
     const int pxb = min(max(gx0 - bx0 + n16, 0), BWMAX - 1);
+    const uint32_t base = lds0 + (uint32_t)(pxb * 512 + kg * 128), c = (uint32_t)((pxb & 7) << 4);
 #pragma unroll
-    for (int s = 0; s < 8; ++s) bo[s] = lds0 + (uint32_t)(pxb * 512 + kg * 128 + ((s ^ (pxb & 7)) << 4));
+    for (int s = 0; s < 8; ++s) bo[s] = base + (c ^ (uint32_t)(s << 4));
   }
   // per accumulator row r4 (pixel 4 kg + r4 of the group): blend weights (the C^-1/2 scale folded into the y weights), the LDS
   // address of row 0 of the image column this lane produces for that pixel, and (in bytes of image rows) where its window starts
@@ -442,15 +455,23 @@ __global__ __launch_bounds__(64 * NW) void local_corr_rows_kernel(LCTileParams p
   }
   if (gvirt) emit_row(float4_t{0.f, 0.f, 0.f, 0.f}, (H - ba0) * ROWB);   // the virtual row below the image
 
-  // ---- write the group's output image: wave-private, no barrier ----
+  // ---- write the group's output image: wave-private, no barrier; 32-bit element offsets from a wave-uniform base ----
   const T* ot = reinterpret_cast<const T*>(ot_all + g * G::OTB);
-  for (int e = lane; e < 16 * K; e += 64) {
-    int m, kk;
-    if (p.out_nhwc) { m = e / K; kk = e - m * K; } else { kk = e >> 4; m = e & 15; }
-    const int oy = gpy + (m >> 2), ox = gpx + (m & 3);
-    if (oy >= H || ox >= W) continue;
-    const size_t o = p.out_nhwc ? (((size_t)b * H + oy) * W + ox) * p.out_pitch + kk : (((size_t)b * p.out_pitch + kk) * H + oy) * W + ox;
-    out[o] = ot[m * (PPB / 2) + N1 + kk];
+  if (p.out_nhwc) {
+    T* ob = out + (((size_t)b * H + gpy) * W + gpx) * p.out_pitch;
+    for (int e = lane; e < 16 * K; e += 64) {
+      const int m = e / K, kk = e - m * K;
+      const int dy = m >> 2, dx = m & 3;
+      if (gpy + dy < H && gpx + dx < W) ob[(uint32_t)((dy * W + dx) * p.out_pitch + kk)] = ot[m * (PPB / 2) + N1 + kk];
+    }
+  } else {
+    T* ob = out + ((size_t)b * p.out_pitch * H + gpy) * W + gpx;
+    const uint32_t plane = (uint32_t)(H * W);
+    for (int e = lane; e < 16 * K; e += 64) {
+      const int kk = e >> 4, m = e & 15;
+      const int dy = m >> 2, dx = m & 3;
+      if (gpy + dy < H && gpx + dx < W) ob[(uint32_t)kk * plane + (uint32_t)(dy * W + dx)] = ot[m * (PPB / 2) + N1 + kk];
+    }
   }
 }
 
@@ -462,7 +483,10 @@ int launch_rows(LCTileParams p, hipStream_t stream) {
   if (int rc = ensure_dyn_smem(reinterpret_cast<const void*>(local_corr_rows_kernel<T, R, NCB, NW>), (int)smem, attr_done, "roma_local_corr")) return rc;
   p.tiles_x = (p.W + kTW - 1) / kTW;
   p.tiles_y = (p.H + 2 * NW - 1) / (2 * NW);
+  p.inv_tiles_per_img = 1.0f / (float)(p.tiles_x * p.tiles_y);
+  p.inv_tiles_x = 1.0f / (float)p.tiles_x;
   const int grid = p.B * p.tiles_x * p.tiles_y;
+  ROMA_REQUIRE(grid < (1 << 21), ROMA_E_SHAPE, "roma_local_corr: %d tiles in one launch (row-streaming kernel: < 2^21)", grid);
   hipLaunchKernelGGL((local_corr_rows_kernel<T, R, NCB, NW>), dim3(grid), dim3(64 * NW), smem, stream, p);
   ROMA_CHECK_LAUNCH();
 }

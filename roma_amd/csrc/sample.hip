@@ -15,12 +15,15 @@ __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
 }
 
 __global__ __launch_bounds__(256) void race_keys_kernel(const float* __restrict__ p, const long* __restrict__ counter,
-                                                        float* __restrict__ keys, long N, float thresh, uint32_t seed) {
+                                                        float* __restrict__ keys, long N, float thresh, uint32_t seed, uint32_t stage) {
+  // the stream of one (seed, stage) pair: mixed non-linearly, so that neither seed + 1 nor the second draw of the same seed is a
+  // shifted copy of this one (round 2 hashed ctr * A + seed * B + C and ran the second draw at seed + 1)
+  const uint32_t stream = fmix32(seed ^ (stage * 0x9E3779B9u));
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
     float w = p[i];
     if (thresh >= 0.f && w > thresh) w = 1.f;
     const uint32_t ctr = (uint32_t)(counter ? counter[i] : i);             // the item's identity, not its position
-    const uint32_t h = fmix32(ctr * 0x9E3779B1u + seed * 0x85EBCA77u + 0x165667B1u);
+    const uint32_t h = fmix32(stream + ctr * 0x9E3779B1u);
     const float u = ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);        // (0, 1), 24 bits, exact in fp32
     const float e = -logf(u);
     keys[i] = (w > 0.f) ? w / e : 0.f;
@@ -67,11 +70,13 @@ extern "C" int roma_nn_argmin(const float* q, const float* r, int* idx, int NQ, 
   ROMA_CHECK_LAUNCH();
 }
 
-extern "C" int roma_race_keys(const float* p, const long* counter, float* keys, long N, float thresh, unsigned seed, void* stream) {
+extern "C" int roma_race_keys(const float* p, const long* counter, float* keys, long N, float thresh, unsigned seed, unsigned stage,
+                              void* stream) {
   ROMA_REQUIRE(p && keys, ROMA_E_ARG, "roma_race_keys: null pointer");
   ROMA_REQUIRE(N > 0, ROMA_E_SHAPE, "roma_race_keys: N must be positive");
   long g = (N + 255) / 256;
   if (g > 8192) g = 8192;
-  hipLaunchKernelGGL(race_keys_kernel, dim3((unsigned)g), dim3(256), 0, static_cast<hipStream_t>(stream), p, counter, keys, N, thresh, (uint32_t)seed);
+  hipLaunchKernelGGL(race_keys_kernel, dim3((unsigned)g), dim3(256), 0, static_cast<hipStream_t>(stream), p, counter, keys, N, thresh, (uint32_t)seed,
+                     (uint32_t)stage);
   ROMA_CHECK_LAUNCH();
 }

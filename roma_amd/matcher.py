@@ -311,6 +311,10 @@ class Decoder(nn.Module):
         # fp64 (diagnostic: removes this side's share of the ill-conditioned solve's error from a parity comparison)
         self.gp_precision = "fp32"
         self.record = None       # a dict here collects diagnostics of the next forward (scale-16 arg-max indices, GP posterior)
+        # DIAGNOSTIC hook (bench.py's roofline_pipeline_coherent): callable(scale, b, h, w, device, upsample) -> (b,2,h,w) fp32 flow
+        # or None; when set, the flow entering that level's refiner is REPLACED by it (so warp and local_correlation see the spatially
+        # coherent flow of a converged matcher instead of what random weights predict).  Never set in the product path.
+        self.flow_override = None
         self._proj = None
 
     def _embedding_decoder_for(self, dtype):
@@ -415,7 +419,8 @@ class Decoder(nn.Module):
                 tokens[:, :n, gp.dim:].copy_(xs)
                 capturing = torch.cuda.is_current_stream_capturing()
                 gp.posterior_rows(xs, ys, hs, ws, fp64=(self.gp_precision == "fp64"), batch_shift=shift,
-                                  out=tokens[:, :n, :gp.dim], check=None if capturing else "defer")   # :377
+                                  out=tokens[:, :n, :gp.dim],
+                                  check=None if capturing else ("defer" if ops.deferring() else "now"))   # :377
                 # The reference runs this transformer under autocast (transformer/__init__.py:31-32): fp32 token / residual
                 # stream and LayerNorm, amp-dtype GEMMs / attention / logits.  Autocast re-casts every weight on every call
                 # (0.26 ms of copy kernels per pair), so the 16-bit modes run a cached copy of the module whose Linear weights
@@ -425,6 +430,10 @@ class Decoder(nn.Module):
                 if self.record is not None and not upsample:
                     self.record["argmax16"] = rows[..., :-1].float().argmax(dim=-1).cpu()     # (b, hw) anchor index (utils.py:316)
                     self.record["mu16"] = tokens[:, :n, :gp.dim].detach().clone()
+            if self.flow_override is not None:
+                forced = self.flow_override(ins, b, hs, ws, device, upsample)
+                if forced is not None:
+                    flow = forced
             flow, certainty = refiner.forward_update(                                         # :393-402
                 x, y, flow, certainty, scale_factor, ins / (self.refine_init * w), ins / (self.refine_init * h), dtype=dtype, buf=buf,
                 batch_shift=shift)
@@ -519,7 +528,7 @@ class RegressionMatcher(nn.Module):
         density = ops.kde(good_matches, std=0.1)                                              # fp16, like the reference (:489)
         p = 1 / (density + 1)
         p[density < 10] = 1e-7
-        bal = torch.topk(ops.race_keys(p, -1.0, seed + 1, counter=good), min(num, len(good_certainty))).indices
+        bal = torch.topk(ops.race_keys(p, -1.0, seed, counter=good, stage=1), min(num, len(good_certainty))).indices
         return good_matches[bal], good_certainty[bal]
 
     # -- coordinates -----------------------------------------------------------------------------
@@ -566,6 +575,10 @@ class RegressionMatcher(nn.Module):
         """P pairs at once.  A_lo,B_lo: (P,3,h,w) normalised coarse images; A_hi,B_hi: (P,3,H,W) for the upsample
         pass.  Returns the stack of per-pair results: warp (P,H,2W,4), certainty (P,H,2W) (symmetric) — the batched
         560->864 semantics the reference leaves undefined (its batched+upsample path raises)."""
+        with ops.deferred_spd_checks():      # the GP solve's SPD check: no host sync in the middle, examined when the pipeline is queued
+            return self._match_tensors(A_lo, B_lo, A_hi, B_hi)
+
+    def _match_tensors(self, A_lo, B_lo, A_hi=None, B_hi=None):
         symmetric = self.symmetric
         # Stream plan.  Only the DINOv2 features feed the first decoder stage (GP + transformer + scale-16 refiner), and
         # that stage is a chain of small, latency-bound kernels.  So the ViT runs first on the main stream, and BOTH VGG
@@ -605,9 +618,7 @@ class RegressionMatcher(nn.Module):
                 batch["pyramid"] = hi_pyr
             corresps = (self.forward_symmetric(batch, upsample=True, scale_factor=scale_factor) if symmetric
                         else self.forward(batch, batched=True, upsample=True, scale_factor=scale_factor))
-        out = ops.match_finalize(corresps[1]["flow"], corresps[1]["certainty"], cert16, symmetric=symmetric)
-        ops.raise_pending()          # the GP solve's SPD check, deferred so that the pipeline has no host sync in the middle
-        return out
+        return ops.match_finalize(corresps[1]["flow"], corresps[1]["certainty"], cert16, symmetric=symmetric)
 
     def make_graphed(self, A_lo, B_lo, A_hi=None, B_hi=None, warmup=2):
         """match_tensors for ONE fixed batch shape as a captured hipGraph (torch.cuda.CUDAGraph is hipGraph on ROCm): the
@@ -654,6 +665,10 @@ class RegressionMatcher(nn.Module):
         hundred microseconds, against ~11 ms of encoder time per pair."""
         if not self.symmetric:
             raise NotImplementedError("match_encoded implements the symmetric mode the shipped models use")
+        with ops.deferred_spd_checks():
+            return self._match_encoded(enc_A, enc_B)
+
+    def _match_encoded(self, enc_A, enc_B):
         pyr = {s: torch.cat((enc_A["lo"][s], enc_B["lo"][s]), dim=0) for s in enc_A["lo"]}
         corresps = self.forward_symmetric({"pyramid": pyr})
         cert16 = corresps[16]["certainty"] if self.attenuate_cert else None
@@ -664,9 +679,7 @@ class RegressionMatcher(nn.Module):
             pyr = {s: torch.cat((enc_A["hi"][s], enc_B["hi"][s]), dim=0) for s in enc_A["hi"]}
             corresps = self.forward_symmetric({"pyramid": pyr, "corresps": corresps[1]}, upsample=True,
                                               scale_factor=math.sqrt(hs * ws / (h * w)))             # matcher.py:677
-        out = ops.match_finalize(corresps[1]["flow"], corresps[1]["certainty"], cert16, symmetric=True)
-        ops.raise_pending()
-        return out
+        return ops.match_finalize(corresps[1]["flow"], corresps[1]["certainty"], cert16, symmetric=True)
 
     @torch.inference_mode()
     def match(self, im_A_input, im_B_input, *args, batched=False, device=None, im_A_hi=None, im_B_hi=None):

@@ -307,9 +307,38 @@ def _raise_if_not_spd(bad):
                                 f"torch.linalg.inv raises here too (matcher.py:261).")
 
 
+_DEFER_DEPTH = [0]
+
+
+def deferring():
+    """True inside `with deferred_spd_checks()`: spd_solve(check="defer") results will be examined when the block ends."""
+    return _DEFER_DEPTH[0] > 0
+
+
+class deferred_spd_checks:
+    """RegressionMatcher.match_tensors / match_encoded wrap their pipeline in this: inside, the GP solve's not-SPD check is an
+    asynchronous copy (no host sync in the middle of the pipeline); when the block ends normally the queued checks are examined
+    (the factorisation finished long before, so the wait is free) and a failure raises there — on the inputs that caused it; when the
+    block ends by an exception the queue is dropped, so nothing stale survives into a later, unrelated call.  Outside such a block
+    the Decoder asks for check="now".  (Nothing is queued while a hipGraph is being captured.)"""
+
+    def __enter__(self):
+        _DEFER_DEPTH[0] += 1
+        return self
+
+    def __exit__(self, et, ev, tb):
+        _DEFER_DEPTH[0] -= 1
+        if _DEFER_DEPTH[0] > 0:
+            return False
+        todo, _PENDING[:] = list(_PENDING), []
+        if et is None and not torch.cuda.is_current_stream_capturing():
+            for chk in todo:
+                _raise_if_not_spd(chk.result())
+        return False
+
+
 def raise_pending():
-    """(No-op while a hipGraph is being captured.)  Examine the deferred spd_solve checks (RegressionMatcher.match_tensors calls this before it returns: by then the
-    factorisation finished long ago, so the wait is free)."""
+    """Examine whatever spd_solve(check="defer") has queued (for callers that defer by hand; no-op while a hipGraph is captured)."""
     if torch.cuda.is_current_stream_capturing():
         return
     todo, _PENDING[:] = list(_PENDING), []
@@ -317,7 +346,7 @@ def raise_pending():
         _raise_if_not_spd(chk.result())
 
 
-def spd_solve(K, F, nb=64, check="now", refine=0):
+def spd_solve(K, F, check="now", refine=0):
     """Solve K X = F for a batch of SPD matrices by a hand-blocked Cholesky: K (B,n,n) fp32, F (B,n,m) fp32.  Replaces
     `inv(K) @ F` of GP.forward (matcher.py:259-263).
 
@@ -341,15 +370,18 @@ def spd_solve(K, F, nb=64, check="now", refine=0):
     check=None skips it.
 
     PYTORCH_TUNABLEOP_ENABLED=1: TunableOp's candidate sweep returned hipErrorInvalidValue for the in-place strided
-    trailing update of an earlier build (gpurun_out/bench_tune.err, round 1); the library calls left in this routine (the fp64
-    residual product, the GEMM fallback for nb != 64) therefore always run with TunableOp switched off (restored afterwards)."""
+    trailing update of an earlier build (gpurun_out/bench_tune.err, round 1); the one library call left in this routine (the fp64
+    residual product of `refine`) therefore always runs with TunableOp switched off (restored afterwards).
+
+    The block size is fixed at 64: roma_chol_step factors the NEXT diagonal block at min(64, n - e) rows whatever the caller's block
+    size, so any other value would overrun the W slots (round 2's `nb` argument was never exercised with anything else and is gone)."""
     _need_gpu(K, F)
     assert K.dtype == torch.float32 and F.dtype == torch.float32
     tun = torch.cuda.tunable.is_enabled()
     if tun:
         torch.cuda.tunable.enable(False)
     try:
-        X, info = _spd_solve(K, F, nb, refine)
+        X, info = _spd_solve(K, F, refine)
     finally:
         if tun:
             torch.cuda.tunable.enable(True)
@@ -360,7 +392,8 @@ def spd_solve(K, F, nb=64, check="now", refine=0):
     return X
 
 
-def _spd_solve(K, F, nb, refine=0):
+def _spd_solve(K, F, refine=0):
+    nb = 64
     B, n, _ = K.shape
     m = F.shape[2]
     lib = _lib.load()
@@ -378,34 +411,24 @@ def _spd_solve(K, F, nb, refine=0):
                                  Rall[:, s].data_ptr(), n + m, Rall.stride(0), None if last else W[:, s + 1].data_ptr(), nb, W.stride(0),
                                  info.data_ptr(), nb * (s + 1), B, _stream()), "roma_chol_step")
     X = torch.empty((B, n, m), dtype=torch.float32, device=K.device)
-    if nb == 64 or len(steps) == 1:
-        S = len(steps)
+    S = len(steps)
 
-        def subst(direction, T, sTb, sTs, ldt, in_panel, out):
-            for s in (range(S - 1, -1, -1) if direction < 0 else range(S)):
-                check(lib.roma_chol_subst_step(direction, W[:, s].data_ptr(), nb, W.stride(0), Rall.data_ptr(), Rall.stride(0), Rall.stride(1),
-                                               n + m, T.data_ptr(), sTb, sTs, ldt, in_panel, out.data_ptr(), m, out.stride(0), n, m, nb, s, B,
-                                               _stream()), "roma_chol_subst_step")
+    def subst(direction, T, sTb, sTs, ldt, in_panel, out):
+        for s in (range(S - 1, -1, -1) if direction < 0 else range(S)):
+            check(lib.roma_chol_subst_step(direction, W[:, s].data_ptr(), nb, W.stride(0), Rall.data_ptr(), Rall.stride(0), Rall.stride(1),
+                                           n + m, T.data_ptr(), sTb, sTs, ldt, in_panel, out.data_ptr(), m, out.stride(0), n, m, nb, s, B,
+                                           _stream()), "roma_chol_subst_step")
 
-        subst(-1, Rall, Rall.stride(0), Rall.stride(1), n + m, 1, X)     # L^T X = Y: one launch per block row, from the bottom up
-        for _ in range(int(refine)):
-            # iterative refinement: residual in fp64 against the fp32-stored K, correction through the finished factor
-            # (forward + back substitution, 2 x S launches; no second factorisation)
-            g = (F.double() - torch.bmm(K.double(), X.double())).float().contiguous()
-            y = torch.empty_like(g)
-            subst(+1, g, g.stride(0), nb * m, m, 0, y)
-            d = torch.empty_like(g)
-            subst(-1, y, y.stride(0), nb * m, m, 0, d)
-            X = X + d
-        return X, info
-    for s in range(len(steps) - 1, -1, -1):                       # other block sizes: two GEMMs per block row
-        j, e = steps[s]
-        w = e - j
-        r = Rall[:, s, :w, :n + m - e]                            # (B, w, (n-e)+m) = [L[e:, j:e]^T | Y[j:e]]
-        t = r[:, :, n - e:]
-        if e < n:
-            t = torch.baddbmm(t, r[:, :, :n - e], X[:, e:], alpha=-1.0)
-        torch.bmm(W[:, s, :w, :w].transpose(1, 2), t, out=X[:, j:e])
+    subst(-1, Rall, Rall.stride(0), Rall.stride(1), n + m, 1, X)     # L^T X = Y: one launch per block row, from the bottom up
+    for _ in range(int(refine)):
+        # iterative refinement: residual in fp64 against the fp32-stored K, correction through the finished factor
+        # (forward + back substitution, 2 x S launches; no second factorisation)
+        g = (F.double() - torch.bmm(K.double(), X.double())).float().contiguous()
+        y = torch.empty_like(g)
+        subst(+1, g, g.stride(0), nb * m, m, 0, y)
+        d = torch.empty_like(g)
+        subst(-1, y, y.stride(0), nb * m, m, 0, d)
+        X = X + d
     return X, info
 
 
@@ -443,17 +466,18 @@ def kde(x, std=0.1, half=True, down=None):
     return dens.half() if half else dens
 
 
-def race_keys(p, thresh=-1.0, seed=0, counter=None):
+def race_keys(p, thresh=-1.0, seed=0, counter=None, stage=0):
     """Exponential-race keys of sampling without replacement (matcher.py:474-493): key_i = w_i / E_i, w_i = 1 where
-    p_i > thresh >= 0 else p_i, E_i ~ Exp(1) from a counter hash of (seed, counter[i] or i).  topk(keys, k) is a draw of k
-    items without replacement with probabilities proportional to w."""
+    p_i > thresh >= 0 else p_i, E_i ~ Exp(1) from a counter hash of (seed, stage, counter[i] or i).  topk(keys, k) is a draw of k
+    items without replacement with probabilities proportional to w.  stage: 0 / 1 = first / second draw of one sample() call."""
     _need_gpu(p, counter)
     p = p.reshape(-1).float().contiguous()
     if counter is not None:
         counter = counter.reshape(-1).long().contiguous()
         assert counter.numel() == p.numel()
     keys = torch.empty_like(p)
-    check(_lib.load().roma_race_keys(_p(p), _p(counter), _p(keys), p.numel(), float(thresh), int(seed) & 0xFFFFFFFF, _stream()), "roma_race_keys")
+    check(_lib.load().roma_race_keys(_p(p), _p(counter), _p(keys), p.numel(), float(thresh), int(seed) & 0xFFFFFFFF,
+                                     int(stage) & 0xFFFFFFFF, _stream()), "roma_race_keys")
     return keys
 
 

@@ -156,7 +156,7 @@ class TinyRoMa(nn.Module):
         density = ops.kde(gm, std=0.1, half=True, down=1)
         p = 1 / (density + 1)
         p[density < 10] = 1e-7
-        bal = torch.topk(ops.race_keys(p, -1.0, seed + 1, counter=good), min(num, len(gc))).indices
+        bal = torch.topk(ops.race_keys(p, -1.0, seed, counter=good, stage=1), min(num, len(gc))).indices
         return gm[bal], gc[bal]
 
 

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_version_and_error_string():
     lib = _lib.load()
-    assert lib.roma_abi_version() == 2
+    assert lib.roma_abi_version() == 3
     assert isinstance(lib.roma_last_error(), bytes)
 
 
@@ -38,7 +38,7 @@ def test_argument_validation_needs_no_gpu():
     assert rc < 0
     rc = lib.roma_add_layernorm(None, 0, 8, None, 0, 8, None, None, None, None, 0, 8, 1, 8, 1e-5, None)
     assert rc == -1 and b"null pointer" in lib.roma_last_error()
-    rc = lib.roma_race_keys(None, None, None, 4, 0.05, 1, None)
+    rc = lib.roma_race_keys(None, None, None, 4, 0.05, 1, 0, None)
     assert rc == -1
     # the fused Cholesky solve (round 2): null pointers, then shapes, are rejected before anything touches a device
     rc = lib.roma_chol_step(None, 8, 64, 8, 8, 0, 8, None, 8, 64, None, 8, 64, None, 8, 64, None, 0, 1, None)

@@ -42,7 +42,7 @@ def solve64(K, F):
 
 def test_library_is_loaded_and_on_gpu():
     from roma_amd import _lib
-    assert _lib.load().roma_abi_version() == 2
+    assert _lib.load().roma_abi_version() == 3
     assert torch.cuda.is_available()
     with pytest.raises(RuntimeError):
         _ops().local_correlation(torch.zeros(1, 8, 4, 4), torch.zeros(1, 8, 4, 4), 2)     # CPU tensors: loud failure
@@ -87,6 +87,39 @@ def test_local_corr_full_sizes_vs_oracle(shape):
     assert maxerr(out, ref) < 5e-5
 
 
+_ORACLE_LC = {}
+
+
+def _oracle_lc_rounded(shape, dtype):
+    """oracle.local_correlation on inputs rounded to `dtype` (what the 16-bit kernels are fed), computed once per (shape, dtype)."""
+    key = (shape, dtype)
+    if key not in _ORACLE_LC:
+        B, C, h, w, r = shape
+        f0 = H.T(R.normal(f"lc16.{shape}.f0", (B, C, h, w))).to(dtype)
+        f1 = H.T(R.normal(f"lc16.{shape}.f1", (B, C, h, w))).to(dtype)
+        flow = H.T(R.coherent_flow(f"lc16.{shape}.flow", B, h, w))
+        _ORACLE_LC[key] = (f0, f1, flow, _O().local_correlation(f0.float(), f1.float(), r, flow=flow))
+    return _ORACLE_LC[key]
+
+
+@pytest.mark.parametrize("variant", ["auto", "tile8x4", "tile8x8", "rows8", "rows16"])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 512, 40, 40, 7), (2, 512, 70, 70, 3), (2, 256, 140, 140, 2), (2, 512, 108, 108, 3), (2, 256, 216, 216, 2)])
+def test_local_corr_16bit_kernels_vs_oracle_at_the_five_call_shapes(shape, dtype, variant):
+    """What bench.py times (16-bit channels-last, AUTO) and every other kernel variant, DIRECTLY against the CPU oracle on the same
+    rounded inputs, at all five 560->864 call shapes of BASELINE.md §3 (L16, L8, L4, U8, U4; B = 2 = one symmetric pair).
+    Tolerance = the output's own rounding."""
+    B, C, h, w, r = shape
+    if r > 3 and variant != "auto":
+        pytest.skip("r = 7 has one 16-bit kernel")
+    f0, f1, flow, ref = _oracle_lc_rounded(shape, dtype)
+    out = _ops().local_correlation(f0.to(DEV).contiguous(memory_format=torch.channels_last),
+                                   f1.to(DEV).contiguous(memory_format=torch.channels_last), r, flow=flow.to(DEV), variant=variant)
+    assert out.dtype == dtype
+    tol = (2 ** -10 if dtype == torch.float16 else 2 ** -7) * max(1.0, float(ref.abs().max()))
+    assert maxerr(out, ref) <= tol
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("shape", [(2, 512, 40, 40, 7), (1, 512, 70, 70, 3), (1, 256, 140, 140, 2), (1, 64, 37, 53, 2), (2, 32, 21, 18, 3),
                                    (1, 96, 30, 44, 7), (1, 256, 216, 216, 2)])
@@ -122,12 +155,13 @@ def test_local_corr_matrix_core_path_vs_fp32_kernel(shape, kind, dtype):
 
 
 @pytest.mark.parametrize("variant", ["tile8x4", "tile8x8", "rows8", "rows16"])
-@pytest.mark.parametrize("shape", [(1, 512, 70, 70, 3), (1, 256, 140, 140, 2), (2, 256, 37, 53, 1), (1, 64, 37, 53, 2), (2, 32, 21, 18, 3)])
+@pytest.mark.parametrize("shape", [(1, 512, 70, 70, 3), (1, 256, 140, 140, 2), (2, 256, 37, 53, 1), (1, 64, 37, 53, 2), (2, 32, 21, 18, 3),
+                                   (2, 256, 19, 45, 3), (1, 512, 21, 9, 2)])
 @pytest.mark.parametrize("kind", ["coherent", "adversarial", "mixed"])
 def test_local_corr_kernel_variants_agree(shape, kind, variant):
-    """The three kernels for 16-bit channels-last inputs with r <= 3 (roma_hip.h: ROMA_LC_*) against the fp32 kernel on the same
+    """The kernels for 16-bit channels-last inputs with r <= 3 (roma_hip.h: ROMA_LC_*) against the fp32 kernel on the same
     rounded inputs, partial border tiles, NaN / far-out-of-range flow entries included.  (A variant that does not apply to a shape
-    — the ring needs C >= 224 — falls back inside the library; the call must still be correct.)"""
+    — the row-streaming kernel needs C = 256 or 512 — falls back inside the library; the call must still be correct.)"""
     B, C, h, w, r = shape
     ops = _ops()
     f0 = H.T(R.normal(f"lcv.{shape}.f0", (B, C, h, w))).half()
@@ -387,6 +421,19 @@ def test_race_keys_match_the_oracle_and_select_the_same_set():
     k_perm = _ops().race_keys(c[perm].to(DEV), 0.05, 3, counter=perm.to(DEV)).cpu()
     assert torch.equal(k_perm, _ops().race_keys(c.to(DEV), 0.05, 3).cpu()[perm])
     assert torch.equal(O.race_keys(c[perm], 0.05, 3, counter=perm), O.race_keys(c, 0.05, 3)[perm])
+    # the two draws of one sample() call are separate streams, and neither is the first draw of the next seed
+    k10 = _ops().race_keys(c.to(DEV), -1.0, 7, stage=0).cpu()
+    k11 = _ops().race_keys(c.to(DEV), -1.0, 7, stage=1).cpu()
+    k20 = _ops().race_keys(c.to(DEV), -1.0, 8, stage=0).cpu()
+    assert not torch.equal(k11, k20) and not torch.equal(k10, k11)
+    ref11 = O.race_keys(c, -1.0, 7, stage=1)
+    assert float(((k11 - ref11).abs() / ref11.clamp_min(1e-30)).max()) < 1e-5
+    pos = c > 0
+    e10, e11, e20 = (torch.log(c[pos] / k[pos]) for k in (k10, k11, k20))       # log of the Exp(1) variates themselves
+
+    def corr(a, b):
+        return float(torch.corrcoef(torch.stack((a, b)))[0, 1])
+    assert abs(corr(e11, e20)) < 0.02 and abs(corr(e10, e20)) < 0.02 and abs(corr(e10, e11)) < 0.02
 
 
 def test_race_keys_are_a_draw_without_replacement_proportional_to_weight():
@@ -445,6 +492,27 @@ def test_batch_shift_equals_explicit_swap():
     rows = f.permute(0, 2, 3, 1).reshape(B, h * w, C)
     srows = swapped.permute(0, 2, 3, 1).reshape(B, h * w, C)
     assert torch.equal(ops.cos_kernel(rows, rows, batch_shift=B // 2), ops.cos_kernel(rows.float().contiguous(), srows.float().contiguous()))
+
+
+@pytest.mark.parametrize("variant", ["rows8", "rows16"])
+def test_local_corr_rows_kernel_on_concat_slices_with_batch_shift_and_identity_flow(variant):
+    """The row-streaming kernel the way the decoder calls it: f0 / f1 are channel slices of wider channels-last buffers (pitch > C,
+    slice not at channel 0), the second operand is the first with its batch halves swapped (batch_shift), the output goes into a
+    slice of the concat buffer; and flow = None (identity grid).  Reference: the fp32 kernel on the same rounded values."""
+    ops = _ops()
+    B, C, h, w, r = 4, 256, 27, 22, 2
+    K = (2 * r + 1) ** 2
+    buf = torch.zeros(B, h, w, 2 * C + K + 15, device=DEV, dtype=torch.float16)
+    d = buf.permute(0, 3, 1, 2)
+    d[:, 8:8 + C] = H.T(R.normal("rows.slice.f", (B, C, h, w)), DEV).half()
+    f = d[:, 8:8 + C]
+    dense = f.float().contiguous(memory_format=torch.channels_last)
+    swapped = torch.cat((dense[B // 2:], dense[:B // 2])).contiguous(memory_format=torch.channels_last)
+    for flow in (H.T(R.coherent_flow("rows.slice.flow", B, h, w), DEV), None):
+        ref = ops.local_correlation(dense, swapped, r, flow=flow)
+        out = ops.local_correlation(f, f, r, flow=flow, batch_shift=B // 2, variant=variant, out=d[:, 8 + C:8 + C + K])
+        assert maxerr(out, ref) <= 2 ** -10 * max(1.0, float(ref.abs().max()))
+        assert float(buf[..., 8 + C + K:].abs().max()) == 0.0 and float(buf[..., :8].abs().max()) == 0.0
 
 
 def test_cos_kernel_reads_channels_last_slices_in_place():
@@ -544,6 +612,35 @@ def test_spd_solve_raises_on_a_matrix_that_is_not_positive_definite():
     with pytest.raises(RomaHipError):
         ops.raise_pending()
     ops.raise_pending()                                                                          # queue is empty again
+    # the scoped form match_tensors / match_encoded use: examined when the block ends, dropped when it ends by an exception
+    with pytest.raises(RomaHipError, match="matrix 1"):
+        with ops.deferred_spd_checks():
+            assert ops.deferring()
+            ops.spd_solve(bad, F, check="defer")
+    assert not ops.deferring()
+    with pytest.raises(KeyError):
+        with ops.deferred_spd_checks():
+            ops.spd_solve(bad, F, check="defer")
+            raise KeyError("something else went wrong in the pipeline")
+    ops.raise_pending()                                                                          # nothing stale is left behind
+    with ops.deferred_spd_checks():
+        ops.spd_solve(K.clone(), F, check="defer")                                               # a good solve passes through
+
+
+def test_chol_step_rejects_a_narrow_block_that_is_not_the_last():
+    """roma_chol_step factors the NEXT diagonal block at min(64, n - e) rows: a caller block size other than 64 is only legal for the
+    last block (nb = 32 used to overrun the W slots)."""
+    from roma_amd import _lib
+    lib = _lib.load()
+    n, m, nb = 100, 4, 32
+    A = torch.zeros(1, n, n + m, device=DEV)
+    W = torch.zeros(1, 4, 64, 64, device=DEV)
+    R = torch.zeros(1, 4, 64, n + m, device=DEV)
+    info = torch.zeros(1, dtype=torch.int32, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    rc = lib.roma_chol_step(A.data_ptr(), A.stride(1), A.stride(0), n, n + m, 0, nb, W.data_ptr(), 64, W.stride(0), R.data_ptr(), n + m,
+                            R.stride(0), W[:, 1].data_ptr(), 64, W.stride(0), info.data_ptr(), nb, 1, st)
+    assert rc == -5 and b"block size 32" in lib.roma_last_error()
 
 
 def test_spd_solve_under_tunableop():

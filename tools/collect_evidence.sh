@@ -7,11 +7,11 @@ O=$R/gpurun_out/evidence
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 echo "[$(date +%T)] kernel trace of bench.py" | tee -a $O/progress.txt
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu > $O/bench_prof.json 2> $O/bench_prof.err
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu > $O/bench_prof.json 2> $O/bench_prof.err
 python3 $R/tools/trace_last_step.py $(ls $O/prof_bench/*/*kernel_trace.csv | head -1) > $O/bench_last_step.md
 cp $(ls $O/prof_bench/*/*kernel_stats.csv | head -1) $O/bench_kernel_stats.csv
 pass() { local name=$1 ctr=$2; shift 2; echo "[$(date +%T)] pass $name: $ctr" | tee -a $O/progress.txt
-  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/pmc_dw/$name -- python3 "$@" > $O/$name.log 2>&1; }
+  timeout -k 5 90 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/pmc_dw/$name -- python3 "$@" > $O/$name.log 2>&1; }   # a rejected counter set hangs the child: never without a timeout
 for cfg in "d576h216 576 216" "d144h432 144 432" "d1144h108 1144 108"; do
   set -- $cfg; tag=$1; shift
   DW="$R/tools/dw_micro.py $*"

@@ -26,7 +26,9 @@ def mean_counter(d, name):
 def source_sha1():
     """Same digest as bench.py's kernel_source_sha1(): all source files of roma_local_corr."""
     h = hashlib.sha1()
-    for f in ("local_corr.hip", "local_corr_t8.hip", "local_corr_ring.hip", "local_corr_ring.h", "lc_device.h"):
+    sys.path.insert(0, ROOT)
+    from bench import LOCAL_CORR_SOURCES                      # one list, one digest
+    for f in LOCAL_CORR_SOURCES:
         h.update(open(os.path.join(ROOT, "roma_amd", "csrc", f), "rb").read())
     return h.hexdigest()
 
