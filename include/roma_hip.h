@@ -32,7 +32,7 @@ extern "C" {
 enum { ROMA_F32 = 0, ROMA_F16 = 1, ROMA_BF16 = 2 };
 enum { ROMA_NCHW = 0, ROMA_NHWC = 1 };
 /* roma_local_corr kernel selection for 16-bit channels-last inputs with r <= 3 (other inputs have one kernel): AUTO picks by launch size */
-enum { ROMA_LC_AUTO = 0, ROMA_LC_TILE8X4 = 1, ROMA_LC_TILE8X8 = 2, ROMA_LC_ROWS8 = 3, ROMA_LC_ROWS16 = 4 };
+enum { ROMA_LC_AUTO = 0, ROMA_LC_TILE8X4 = 1, ROMA_LC_TILE8X8 = 2, ROMA_LC_ROWS8 = 3 };
 enum { ROMA_E_ARG = -1, ROMA_E_DTYPE = -2, ROMA_E_SHAPE = -3, ROMA_E_ALIGN = -4, ROMA_E_UNSUPPORTED = -5 };
 
 int roma_abi_version(void);
@@ -46,7 +46,7 @@ const char* roma_last_error(void);
  *   r in {1..7}.  f1_batch_shift: f0's item b is correlated with f1's item (b + f1_batch_shift) % B — B/2 for
  *   forward_symmetric (matcher.py:516-528), whose second operand is the first with its batch halves swapped; 0 otherwise.
  *   variant: ROMA_LC_AUTO, or one of the kernels for 16-bit channels-last inputs with r <= 3 (8x4 / 8x8 tiles staged in 32-channel
- *   chunks; ROWS8 / ROWS16 = row-streaming kernel on 8x8 / 8x16 tiles, C = 256 or 512, else the 8x8 chunk kernel).  Same results
+ *   chunks; ROWS8 = the row-streaming kernel on 8x8 tiles, C = 256 or 512, else the 8x8 chunk kernel).  Same results
  *   to fp32 summation order; ignored where only one kernel applies. */
 int roma_local_corr(const void* f0, const void* f1, const float* flow, void* out,
                     int B, int C, int H, int W, int r, int dtype,

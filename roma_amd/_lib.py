@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libroma_hip.so")
 
 ROMA_F32, ROMA_F16, ROMA_BF16 = 0, 1, 2
 ROMA_NCHW, ROMA_NHWC = 0, 1
-LC_VARIANTS = {"auto": 0, "tile8x4": 1, "tile8x8": 2, "rows8": 3, "rows16": 4}
+LC_VARIANTS = {"auto": 0, "tile8x4": 1, "tile8x8": 2, "rows8": 3}
 ABI_VERSION = 3
 
 # name -> argtypes; restype is c_int unless listed in _RESTYPES.  Mirrors include/roma_hip.h one to one.

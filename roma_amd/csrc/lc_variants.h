@@ -21,8 +21,9 @@ struct LCTileParams {
 
 // one 8x8 tile per workgroup (local_corr_t8.hip): 16-bit channels-last inputs, r in 1..3, C a multiple of 32
 int local_corr_t8(const LCTileParams& p, int r, int dtype, hipStream_t stream);
-// row-streaming kernel (local_corr_rows.hip): 16-bit channels-last inputs, r in 1..3, C = 256 or 512; tile_h = 8 or 16
-bool local_corr_rows_supports(int C);
-int local_corr_rows(const LCTileParams& p, int r, int dtype, int tile_h, hipStream_t stream);
+// row-streaming kernel (local_corr_rows.hip), 8x8 tiles: 16-bit channels-last inputs, C = 256 or 512, r in 1..3, or r = 7 on maps up to
+// 47 pixels wide (no patch path there: every tile streams)
+bool local_corr_rows_supports(int C, int r, int H, int W);
+int local_corr_rows(const LCTileParams& p, int r, int dtype, hipStream_t stream);
 
 }  // namespace roma

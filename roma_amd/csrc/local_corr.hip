@@ -903,34 +903,31 @@ int launch_any(const LCParams& p, hipStream_t s) {
   constexpr int CC = 4 * ElemTraits<T>::kPer16B;                // the fast paths stream whole 64-byte channel chunks
   if (!(p.in_nhwc && p.C % CC == 0)) return launch_lc<T, R>(p, s);
   if constexpr (sizeof(T) == 2) {
-    if constexpr (R <= 3) {
-      // Kernels for this case; `variant` (roma_hip.h) picks one, AUTO by launch size:
-      //   8x4 tiles, 32-channel chunks (below): 4-5 workgroups per CU hide the per-tile fixed latencies; best on small launches
-      //     and on incoherent flow (its per-pixel-patch path keeps the highest occupancy);
-      //   8x8 tiles, 32-channel chunks (local_corr_t8.hip): half the fixed cost per pixel, register epilogue;
-      //   row streaming, 8x8 or 8x16 tiles (local_corr_rows.hip, C = 256 / 512): whole 512-byte pixel rows through a 4-slot LDS
-      //     ring, f0 in registers.
-      // AUTO: the row-streaming kernel wherever it applies (coherent flow, the regime of a trained matcher: 26.6 vs 20.9 % of 8 TB/s at
-      // one pair per launch, 42.4 vs 35.2 % at 16 pairs; on fully incoherent flow its patch path runs at 3 workgroups per CU and is
-      // ~20 % behind the 8x4-tile kernel's: gpurun_out/r3_lcb5*.txt); otherwise by launch size as before.
-      const int nt8 = p.B * ((p.H + 7) / 8) * ((p.W + 7) / 8);
-      // the tile kernels address one feature map with 32-bit byte offsets
-      const bool t8_ok = p.C % 32 == 0 && (size_t)p.H * p.W * (size_t)(p.f0_pitch > p.f1_pitch ? p.f0_pitch : p.f1_pitch) * 2 < (1ull << 32);
-      const bool rows_ok = t8_ok && local_corr_rows_supports(p.C) && nt8 < (1 << 21);
-      int v = p.variant;
-      if (v == ROMA_LC_AUTO) v = rows_ok ? ROMA_LC_ROWS8 : (p.C % 32 == 0 && nt8 >= 2048) ? ROMA_LC_TILE8X8 : ROMA_LC_TILE8X4;
-      if ((v == ROMA_LC_ROWS8 || v == ROMA_LC_ROWS16) && !rows_ok) v = ROMA_LC_TILE8X8;
-      if (v == ROMA_LC_TILE8X8 && !t8_ok) v = ROMA_LC_TILE8X4;
-      if (v != ROMA_LC_TILE8X4) {
-        LCTileParams q{};
-        q.f0 = p.f0; q.f1 = p.f1; q.flow = p.flow; q.out = p.out;
-        q.B = p.B; q.C = p.C; q.H = p.H; q.W = p.W;
-        q.f0_pitch = p.f0_pitch; q.f1_pitch = p.f1_pitch; q.out_pitch = p.out_pitch;
-        q.out_nhwc = p.out_nhwc; q.f1_shift = p.f1_shift; q.scale = p.scale;
-        const int dt = std::is_same<T, half_t>::value ? ROMA_F16 : ROMA_BF16;
-        if (v == ROMA_LC_TILE8X8) return local_corr_t8(q, R, dt, s);
-        return local_corr_rows(q, R, dt, v == ROMA_LC_ROWS16 ? 16 : 8, s);
-      }
+    // Kernels for this case; `variant` (roma_hip.h) picks one, AUTO:
+    //   row streaming (local_corr_rows.hip, 8x8 tiles, C = 256 / 512; r <= 3, or r = 7 on maps up to 47 wide): whole 512-byte
+    //     pixel rows through an LDS ring, f0 in registers — AUTO wherever it applies (coherent flow, the regime of a trained matcher:
+    //     26.6 vs 20.9 % of 8 TB/s at one pair per launch, 42.4 vs 35.2 % at 16 pairs; on fully incoherent flow its r <= 3 patch path
+    //     runs at 3 workgroups per CU, ~20 % behind the 8x4-tile kernel's: gpurun_out/r3_lcb5*.txt);
+    //   8x4 tiles, 32-channel chunks (below): 4-5 workgroups per CU hide the per-tile fixed latencies;
+    //   8x8 tiles, 32-channel chunks (local_corr_t8.hip, r <= 3): half the fixed cost per pixel, register epilogue.
+    const int nt8 = p.B * ((p.H + 7) / 8) * ((p.W + 7) / 8);
+    // the tile kernels address one feature map with 32-bit byte offsets
+    const bool t8_ok = R <= 3 && p.C % 32 == 0 && (size_t)p.H * p.W * (size_t)(p.f0_pitch > p.f1_pitch ? p.f0_pitch : p.f1_pitch) * 2 < (1ull << 32);
+    const bool rows_ok = local_corr_rows_supports(p.C, R, p.H, p.W) && nt8 < (1 << 21) &&
+                         (size_t)p.H * p.W * (size_t)(p.f0_pitch > p.f1_pitch ? p.f0_pitch : p.f1_pitch) * 2 < (1ull << 32);
+    int v = p.variant;
+    if (v == ROMA_LC_AUTO) v = rows_ok ? ROMA_LC_ROWS8 : (t8_ok && nt8 >= 2048) ? ROMA_LC_TILE8X8 : ROMA_LC_TILE8X4;
+    if (v == ROMA_LC_ROWS8 && !rows_ok) v = ROMA_LC_TILE8X8;
+    if (v == ROMA_LC_TILE8X8 && !t8_ok) v = ROMA_LC_TILE8X4;
+    if (v != ROMA_LC_TILE8X4) {
+      LCTileParams q{};
+      q.f0 = p.f0; q.f1 = p.f1; q.flow = p.flow; q.out = p.out;
+      q.B = p.B; q.C = p.C; q.H = p.H; q.W = p.W;
+      q.f0_pitch = p.f0_pitch; q.f1_pitch = p.f1_pitch; q.out_pitch = p.out_pitch;
+      q.out_nhwc = p.out_nhwc; q.f1_shift = p.f1_shift; q.scale = p.scale;
+      const int dt = std::is_same<T, half_t>::value ? ROMA_F16 : ROMA_BF16;
+      if (v == ROMA_LC_TILE8X8) return local_corr_t8(q, R, dt, s);
+      return local_corr_rows(q, R, dt, s);
     }
     return launch_lc_mfma<T, R>(p, s);
   } else {
@@ -964,7 +961,7 @@ extern "C" int roma_local_corr(const void* f0, const void* f1, const float* flow
   ROMA_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, ROMA_E_SHAPE, "roma_local_corr: bad shape B=%d C=%d H=%d W=%d", B, C, H, W);
   ROMA_REQUIRE(r >= 1 && r <= 7, ROMA_E_UNSUPPORTED, "roma_local_corr: radius %d outside 1..7", r);
   ROMA_REQUIRE(f1_batch_shift >= 0 && f1_batch_shift < B, ROMA_E_ARG, "roma_local_corr: f1_batch_shift %d outside [0, B)", f1_batch_shift);
-  ROMA_REQUIRE(variant >= ROMA_LC_AUTO && variant <= ROMA_LC_ROWS16, ROMA_E_ARG, "roma_local_corr: unknown kernel variant %d", variant);
+  ROMA_REQUIRE(variant >= ROMA_LC_AUTO && variant <= ROMA_LC_ROWS8, ROMA_E_ARG, "roma_local_corr: unknown kernel variant %d", variant);
   ROMA_REQUIRE(layout == ROMA_NCHW || layout == ROMA_NHWC, ROMA_E_ARG, "roma_local_corr: bad layout %d", layout);
   ROMA_REQUIRE(out_layout == ROMA_NCHW || out_layout == ROMA_NHWC, ROMA_E_ARG, "roma_local_corr: bad out_layout %d", out_layout);
   const int K = (2 * r + 1) * (2 * r + 1);

@@ -19,8 +19,10 @@
 //     8 accumulator registers instead of 48-64, and the box may be as tall as it likes;
 //   * image borders need no second code path: out-of-image box columns are staged from a clamped address and zeroed by a select,
 //     out-of-image rows are not staged at all (the previous-row registers start at zero; one virtual row below the image).
-// Tiles whose targets are not compact (box wider than BWMAX, a group wider than 16 columns) take per-pixel patches on the VALU as in
-// the other kernels.  Tile = 8 x TH pixels, TH = 8 (4 waves) or 16 (8 waves: 3.0 instead of 3.9 staged f1 rows per pixel).
+// Tiles whose targets are not compact (box wider than BWMAX, a group wider than 16 columns) gather one patch per pixel through the same
+// ring (patch path below).  r = 7 on small maps (the 40 x 40 scale-16 level): up to three column blocks per group and a box that may be
+// the whole map, so every tile streams.  Tile = 8 x 8 pixels, 4 waves (an 8 x 16 / 8-wave variant measured 1.5-2x slower: its waves
+// idle through half of the 26 stages and 150 VGPRs leave one workgroup per CU at C = 512; gpurun_out/r3_lcb3.txt).
 #include "common.h"
 #include "lc_device.h"
 #include "lc_variants.h"
@@ -30,22 +32,17 @@ namespace {
 
 using namespace lc;
 
-template <int R> struct SlowGeom {
-  static constexpr int N2 = 2 * R + 2, Q = N2 * N2, QP = Q;
-  static constexpr int NIT = (Q + 15) / 16;
-  static constexpr int SB = R <= 2 ? 8 : 4;                    // pixels per pass
-  static constexpr int UB = (SB * NIT + 15) / 16;
-  static constexpr int USED = kTP + SB * QP;                   // f0 rows + patches (64-byte rows)
-  static constexpr int SNL = (USED * 4 + 255) / 256;           // DMA rounds per chunk: 64 rows each, whole rounds are written
-  static constexpr int ZROW = SNL * 64;                        // first all-zero row, behind everything the DMA touches
-  static constexpr int ROWS = ZROW + 16;
-};
-
 template <int R, int NW> struct RowsGeom {
   static constexpr int N1 = 2 * R + 1, K = N1 * N1;
-  static constexpr int BWMAX = 20;                             // widest staged box (pixels)
+  // r <= 3: one 16-column MFMA block per group, boxes up to 20 pixels wide, patch path for what does not fit.
+  // r >= 4 (the 40 x 40 / r = 7 level): up to three blocks per group and a box as wide as the whole map (W <= 47, host check), so
+  // EVERY tile streams, however incoherent the flow — at that size a box that is the whole image (1.6 MB per tile) is a tenth of what
+  // 64 private 16 x 16 patches cost.
+  static constexpr int NBLK = R <= 3 ? 1 : 3;
+  static constexpr int BWMAX = R <= 3 ? 20 : 48;               // widest staged box (pixels); a multiple of 2 NW: whole DMA rounds
   static constexpr int SLOTB = BWMAX * 512;                    // one stage: BWMAX pixels x 256 channels
   static constexpr int NS = 4;                                 // ring slots; NS - 2 stages in flight beside the one being read
+  static constexpr bool kPatchPath = R <= 3;
   static constexpr int PF = NS - 2;
   static constexpr int RINGB = NS * SLOTB;
   static constexpr int NIT = SLOTB / 1024;                     // DMA wave-instructions per stage (two pixels each)
@@ -57,142 +54,11 @@ template <int R, int NW> struct RowsGeom {
   static constexpr int PPB = TR * N1 * 2;                      // bytes per pixel slot
   static constexpr int OTB = ((17 * PPB + 15) / 16) * 16;
   static constexpr int NPIX = 16 * NW;
-  static constexpr int SROWB = SlowGeom<R>::ROWS * 64, SDB = kTP * (SlowGeom<R>::Q + 1) * 4;
-  static constexpr int REGA = RINGB > SROWB + SDB ? RINGB : SROWB + SDB;   // ring | the patch path's rows + window images
+  static constexpr int REGA = RINGB;                           // the ring (streaming path and patch path alike)
   static constexpr int REGB = NW * OTB;                        // output images
   static constexpr int SMEM = REGA + REGB + 4 * NPIX * 4 + NW * 8 * 4;
   static constexpr int MAXROWS = 96;                           // tallest box that still streams (beyond: patches)
 };
-
-// ---- incoherent 8x8 sub-tile: per-pixel patches on the VALU (the chunk kernels' path; 256 threads, the others only keep the
-// barrier count).  s_* point at the sub-tile's 64 entries, group-major.
-template <typename T, int R>
-__device__ __forceinline__ void slow_subtile(const LCTileParams& p, unsigned char* region, unsigned char* region_d, const int* s_x0, const int* s_y0,
-                                             const float* s_ax, const float* s_ay, int tid, int wave, int lane, bool active,
-                                             int b, int ty0, int tx0, const T* f0, const T* f1, T* out) {
-  using S = SlowGeom<R>;
-  constexpr int N1 = 2 * R + 1, N2 = S::N2, Q = S::Q, K = N1 * N1, QP = S::QP, NIT = S::NIT, SB = S::SB, UB = S::UB, SNL = S::SNL;
-  constexpr int ZROW = S::ZROW, E16 = 8, CC = 32;
-  const int H = p.H, W = p.W;
-  u32x4* rows = reinterpret_cast<u32x4*>(region);
-  float* s_D = reinterpret_cast<float*>(region_d);
-  const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)region;
-  int g16 = 0, idx = 0;                                         // 16-lane ds_read_b128 service groups of a wavefront
-  {
-    const int l5 = lane & 31;
-    int hg;
-    if (l5 < 4) { hg = 0; idx = l5; }
-    else if (l5 < 12) { hg = 1; idx = l5 - 4; }
-    else if (l5 < 16) { hg = 0; idx = l5 - 8; }
-    else if (l5 < 20) { hg = 1; idx = l5 - 8; }
-    else if (l5 < 28) { hg = 0; idx = l5 - 12; }
-    else { hg = 1; idx = l5 - 16; }
-    g16 = wave * 4 + (lane >> 5) * 2 + hg;
-  }
-  if (active) {
-    for (int i = tid; i < 64; i += 256) rows[ZROW * 4 + i] = u32x4{0, 0, 0, 0};
-    for (int i = tid; i < kTP * (Q + 1); i += 256) s_D[i] = 0.f;
-  }
-  __syncthreads();
-  for (int pass = 0; pass < kTP / SB; ++pass) {
-    int pixw[UB], qw[UB], rowidx[UB];
-    float sacc[UB];
-    const T* ssrc[SNL];
-    constexpr int used_rows = S::USED;
-    if (active) {
-#pragma unroll
-      for (int w = 0; w < UB; ++w) {
-        const int uu = g16 + 16 * w;
-        const int sl = uu / NIT, it = uu - sl * NIT;
-        int pix = (uu < SB * NIT) ? pass * SB + sl : kTP;
-        const bool pact = pix < kTP;
-        pix = pact ? pix : 0;
-        int py, px;
-        fpix(pix, py, px);
-        const bool pvalid = pact && (ty0 + py < H) && (tx0 + px < W);
-        const int q = it * 16 + idx;
-        const int yy = s_y0[pix] - R + q / N2, xx = s_x0[pix] - R + q % N2;
-        const bool qok = pvalid && (q < Q) && (yy >= 0) && (yy < H) && (xx >= 0) && (xx < W);
-        pixw[w] = pvalid ? pix : -1;
-        qw[w] = q;
-        rowidx[w] = qok ? kTP + sl * QP + q : ZROW;
-        sacc[w] = 0.f;
-      }
-#pragma unroll
-      for (int l = 0; l < SNL; ++l) {
-        const int slot = l * 256 + tid;
-        const int row = slot >> 2;
-        const int kk = (slot & 3) ^ ((row >> 2) & 1);
-        int y = ty0, x = tx0, pitch = p.f0_pitch;
-        const T* base = f0;
-        y = min(y, H - 1);
-        x = min(x, W - 1);
-        if (row < kTP) {
-          int py, px;
-          fpix(row, py, px);
-          y = min(ty0 + py, H - 1);
-          x = min(tx0 + px, W - 1);
-        } else if (row < used_rows) {
-          const int rr = row - kTP;
-          const int sl = rr / QP, q = rr - sl * QP;
-          const int pix = pass * SB + sl;
-          if (q < Q) {
-            y = min(max(s_y0[pix] - R + q / N2, 0), H - 1);
-            x = min(max(s_x0[pix] - R + q % N2, 0), W - 1);
-            base = f1;
-            pitch = p.f1_pitch;
-          }
-        }
-        ssrc[l] = base + ((size_t)y * W + x) * pitch + kk * E16;
-      }
-    }
-    for (int c0 = 0; c0 < p.C; c0 += CC) {
-      if (active) {
-#pragma unroll
-        for (int l = 0; l < SNL; ++l)
-          if (l * 64 < used_rows) dma16(ssrc[l] + c0, lds0 + (uint32_t)(l * 256 + wave * 64) * 16);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      __syncthreads();
-      if (active) {
-#pragma unroll
-        for (int w = 0; w < UB; ++w) {
-          const int prow = pixw[w] < 0 ? 0 : pixw[w];
-          const int r0 = rowidx[w];
-          float s = sacc[w];
-#pragma unroll
-          for (int kk = 0; kk < 4; ++kk) s = dot16<T>(rows[swzr(prow, kk)], rows[swzr(r0, kk)], s);
-          sacc[w] = s;
-        }
-      }
-      __syncthreads();
-    }
-    if (active) {
-#pragma unroll
-      for (int w = 0; w < UB; ++w)
-        if (qw[w] < Q && pixw[w] >= 0) s_D[pixw[w] * (Q + 1) + qw[w]] = sacc[w] * p.scale;
-    }
-  }
-  __syncthreads();
-  if (active) {
-    for (int e = tid; e < kTP * K; e += 256) {
-      int row, kk;
-      if (p.out_nhwc) { row = e / K; kk = e - row * K; } else { kk = e / kTP; row = e - kk * kTP; }
-      int py, px;
-      fpix(row, py, px);
-      const int y = ty0 + py, x = tx0 + px;
-      if (y >= H || x >= W) continue;
-      const int iy = kk / N1, ix = kk - iy * N1;
-      const float ax = s_ax[row], ay = s_ay[row];
-      const float* d = s_D + row * (Q + 1) + iy * N2 + ix;
-      const float top = d[0] + ax * (d[1] - d[0]);
-      const float bot = d[N2] + ax * (d[N2 + 1] - d[N2]);
-      const size_t o = p.out_nhwc ? (((size_t)b * H + y) * W + x) * p.out_pitch + kk : (((size_t)b * p.out_pitch + kk) * H + y) * W + x;
-      out[o] = from_f32<T>(top + ay * (bot - top));
-    }
-  }
-  __syncthreads();
-}
 
 // one LDS-DMA wave-instruction without the M0 save / restore of lc::dma16_so: nothing else in this kernel uses M0
 __device__ __forceinline__ void dma_row(const void* sbase, uint32_t voff, uint32_t lds_wave_base) {
@@ -204,6 +70,10 @@ typedef __attribute__((address_space(3))) unsigned char lds_u8;
 
 // min / max over each row of 16 lanes, result in every lane: four DPP steps on the VALU (quad xor 1, quad xor 2, half-row mirror, row
 // mirror) instead of four ds_bpermute round trips through the LDS pipe
+// lane i <- lane (i + 1) mod 16 inside each row of 16 lanes (DPP row_ror:15)
+__device__ __forceinline__ float rot_left(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x12F, 0xf, 0xf, false));
+}
 template <int CTRL> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
 __device__ __forceinline__ int row16_min(int v) {
   v = min(v, dpp_i<0xB1>(v)); v = min(v, dpp_i<0x4E>(v)); v = min(v, dpp_i<0x141>(v)); return min(v, dpp_i<0x140>(v));
@@ -216,7 +86,7 @@ template <typename T, int R, int NCB, int NW>
 __global__ __launch_bounds__(64 * NW) void local_corr_rows_kernel(LCTileParams p) {
   using G = RowsGeom<R, NW>;
   constexpr int N1 = G::N1, K = G::K, TH = 2 * NW, NIW = G::NIW, NPIX = G::NPIX, SLOTB = G::SLOTB, BWMAX = G::BWMAX;
-  constexpr int NS = G::NS, PF = G::PF, PPB = G::PPB;
+  constexpr int NS = G::NS, PF = G::PF, PPB = G::PPB, NBLK = G::NBLK;
   constexpr int UNR = NS * NCB;                                  // stages per unrolled block: slot and channel block are compile-time
   constexpr int BIG = 0x3fffffff;
 
@@ -303,7 +173,7 @@ __global__ __launch_bounds__(64 * NW) void local_corr_rows_kernel(LCTileParams p
   if (lane == 0) {
     int* gb = s_gbox + g * 8;
     gb[0] = gx0; gb[1] = gx1; gb[2] = ga0; gb[3] = ga1;
-    gb[4] = gempty || gx1 - gx0 + 1 <= 16;
+    gb[4] = gempty || gx1 - gx0 + 1 <= 16 * NBLK;
     gb[5] = gempty;
   }
   __syncthreads();
@@ -322,14 +192,201 @@ __global__ __launch_bounds__(64 * NW) void local_corr_rows_kernel(LCTileParams p
   const int nrows = __builtin_amdgcn_readfirstlane(tempty ? 0 : max(ba1 - ba0 + 1, 0));
   ok = ok && bw <= BWMAX && nrows <= G::MAXROWS;
 
-  if (!__builtin_amdgcn_readfirstlane((int)ok)) {
-    // =========================== incoherent tile: per-pixel patches, one 8x8 sub-tile after the other ===========================
-#pragma unroll 1
-    for (int sub = 0; sub < NW / 4; ++sub)
-      slow_subtile<T, R>(p, smem, smem + G::SROWB, s_x0 + sub * 64, s_y0 + sub * 64, s_ax + sub * 64, s_ay + sub * 64, tid & 255, wave & 3, lane,
-                         wave < 4, b, ty0 + sub * 8, tx0, f0, f1, out);
-    return;
+  if constexpr (G::kPatchPath) {
+    if (!__builtin_amdgcn_readfirstlane((int)ok)) {
+      // =========================== incoherent tile: every pixel gathers its own (2r+2)^2 patch ===========================
+      // Same ring, same whole-row DMAs, same A registers as the streaming path; a stage is PR rows of ONE pixel's patch (16-18
+      // positions x 256 channels).  All waves stage, the wave that owns the pixel's group multiplies (the 16 x 16 MFMA computes the
+      // stage's positions against all 16 pixels of the group; the pixel's own row is kept), and when the pixel's last stage is done
+      // that wave blends the patch in a 256-byte LDS image of its own and stores the K outputs.  Pixels outside the image or whose
+      // window misses the map are not staged at all (their outputs are zero).  The 32-channel-chunk kernels gather 64-byte pieces
+      // (10-12 TB/s ceiling, tools/stage_micro.hip); whole 512-byte rows reach 14-16.
+      constexpr int N2 = 2 * R + 2;
+      constexpr int PR = R == 1 ? 4 : R == 2 ? 3 : 2;             // patch rows per stage
+      constexpr int PPS = PR * N2;                                // positions per stage: 16 / 18 / 16
+      constexpr int SPP = N2 / PR;                                // stages per pixel and channel block: 1 / 2 / 4
+      constexpr int NB2 = (PPS + 15) / 16;                        // MFMA column blocks per stage
+      constexpr int NIT2 = (PPS + 1) / 2;                         // DMA wave-instructions per stage
+      constexpr int NIW2 = (NIT2 + NW - 1) / NW;
+      constexpr int NREG = NPIX / 64;                             // pixel records per lane (1 at 8x8 tiles, 2 at 8x16)
+      static_assert(PPS <= BWMAX && N2 % PR == 0 && K <= 64, "patch stage geometry");
+      // every wave keeps every pixel's target: record j = m NW + g (so that consecutive records belong to different waves)
+      int rx0[NREG], ry0[NREG];
+      float rax[NREG], ray[NREG];
+      unsigned long long act[NREG];
+#pragma unroll
+      for (int q = 0; q < NREG; ++q) {
+        const int j = q * 64 + lane, gg = j % NW, mm = j / NW, r = gg * 16 + mm;
+        rx0[q] = s_x0[r]; ry0[q] = s_y0[r]; rax[q] = s_ax[r]; ray[q] = s_ay[r];
+        const int py = ty0 + (gg >> 1) * 4 + (mm >> 2), px = tx0 + (gg & 1) * 4 + (mm & 3);
+        const bool hit = py < H && px < W && max(rx0[q] - R, 0) <= min(rx0[q] + R + 1, W - 1) && max(ry0[q] - R, 0) <= min(ry0[q] + R + 1, H - 1);
+        act[q] = __ballot(hit);
+      }
+      // zeros for this wave's pixels that are inside the image but gather nothing
+      {
+        T* ob = p.out_nhwc ? out + (((size_t)b * H + gpy) * W + gpx) * p.out_pitch : out + ((size_t)b * p.out_pitch * H + gpy) * W + gpx;
+        const uint32_t plane = (uint32_t)(H * W);
+        for (int mm = 0; mm < 16; ++mm) {
+          const int j = mm * NW + g;
+          const bool on = (act[j >> 6] >> (j & 63)) & 1ull;
+          const int dy = mm >> 2, dx = mm & 3;
+          if (on || gpy + dy >= H || gpx + dx >= W) continue;   // wave-uniform
+          if (lane < K) ob[p.out_nhwc ? (uint32_t)((dy * W + dx) * p.out_pitch + lane) : (uint32_t)lane * plane + (uint32_t)(dy * W + dx)] = from_f32<T>(0.f);
+        }
+      }
+      int npx = 0;
+#pragma unroll
+      for (int q = 0; q < NREG; ++q) npx += __builtin_popcountll(act[q]);
+      npx = __builtin_amdgcn_readfirstlane(npx);
+      const int nst = npx * SPP * NCB;
+      // DMA plan: instruction ii = k NW + wave covers positions 2 ii, 2 ii + 1 of the stage
+      int dyk[NIW2], dxk[NIW2];
+      uint32_t coff[NIW2];
+#pragma unroll
+      for (int k = 0; k < NIW2; ++k) {
+        const int P = (k * NW + wave) * 64 + lane;
+        const int pos = P >> 5, qp = P & 31;
+        const int posc = min(pos, PPS - 1);
+        dyk[k] = posc / N2; dxk[k] = posc - dyk[k] * N2;
+        coff[k] = (uint32_t)(((qp & 24) | ((qp ^ pos) & 7)) * 16);
+      }
+      constexpr int n_lo = NIW2 - 1;
+      const bool hi_share = wave < NIT2 - n_lo * NW;             // waves that issue NIW2 instructions per stage, the others one fewer
+      // B fragment addresses: position 16 blk + n16 of the stage
+      uint32_t bo2[NB2][8];
+#pragma unroll
+      for (int blk = 0; blk < NB2; ++blk) {
+        const int pos = min(16 * blk + n16, BWMAX - 1);
+        const uint32_t base = lds0 + (uint32_t)(pos * 512 + kg * 128), c = (uint32_t)((pos & 7) << 4);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) bo2[blk][s] = base + (c ^ (uint32_t)(s << 4));
+      }
+      float* pd = reinterpret_cast<float*>(ot_all + g * G::OTB);  // this wave's patch image: Q products of the pixel in hand
+      static_assert(G::OTB >= (int)((2 * R + 2) * (2 * R + 2) * 4), "patch image fits the group's output image");
+
+      // the n-th active pixel record, in record order: a cursor over the activity masks, advanced by the issuing side and (PF stages
+      // later) by the computing side
+      struct Cursor { unsigned long long m[NREG]; int q; };
+      auto cur_init = [&](Cursor& c) {
+#pragma unroll
+        for (int q = 0; q < NREG; ++q) c.m[q] = act[q];
+        c.q = 0;
+      };
+      auto cur_peek = [&](Cursor& c) -> int {                     // record index of the next active pixel (there is one)
+        if (NREG > 1 && c.m[0] == 0 && c.q == 0) c.q = 1;
+        const unsigned long long mk = NREG > 1 && c.q == 1 ? c.m[NREG - 1] : c.m[0];
+        return c.q * 64 + __builtin_ctzll(mk);
+      };
+      auto cur_pop = [&](Cursor& c) {
+        if (NREG > 1 && c.q == 1) c.m[NREG - 1] &= c.m[NREG - 1] - 1; else c.m[0] &= c.m[0] - 1;
+      };
+      auto rec_i = [&](const int* v, int j) -> int {
+        return NREG > 1 && j >= 64 ? __builtin_amdgcn_readlane(v[NREG - 1], j - 64) : __builtin_amdgcn_readlane(v[0], j & 63);
+      };
+      auto rec_f = [&](const float* v, int j) -> float {
+        return __builtin_bit_cast(float, NREG > 1 && j >= 64 ? __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[NREG - 1]), j - 64)
+                                                            : __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[0]), j & 63));
+      };
+
+      auto run_patches = [&](auto nwi_c) {
+        constexpr int NWI = decltype(nwi_c)::value;
+        const uint32_t dst0 = lds0 + (uint32_t)(wave * 1024);
+        Cursor ci, cc;
+        cur_init(ci); cur_init(cc);
+        int ist = 0;                                              // stages issued so far
+        auto issue = [&](auto slot_c, auto cb_c) {
+          constexpr int SLOT = decltype(slot_c)::value, CB = decltype(cb_c)::value;
+          const int j = cur_peek(ci);
+          const int part = (ist / NCB) & (SPP - 1);
+          const int x0j = rec_i(rx0, j) - R, y0j = rec_i(ry0, j) - R + part * PR;
+#pragma unroll
+          for (int k = 0; k < NWI; ++k) {
+            const int yy = min(max(y0j + dyk[k], 0), H - 1), xx = min(max(x0j + dxk[k], 0), W - 1);
+            dma_row(f1 + CB * 256, (uint32_t)((yy * W + xx) * p.f1_pitch) * 2u + coff[k], dst0 + (uint32_t)(SLOT * SLOTB + k * NW * 1024));
+          }
+          ++ist;
+          if ((ist & (SPP * NCB - 1)) == 0) cur_pop(ci);
+        };
+        float4_t acc2[NB2];
+        if (PF >= 1 && nst > 0) issue(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        if (PF >= 2 && nst > 1) issue(std::integral_constant<int, 1 % NS>{}, std::integral_constant<int, 1 % NCB>{});
+        for (int st0 = 0; st0 < nst; st0 += UNR) {
+#pragma unroll
+          for (int u = 0; u < UNR; ++u) {
+            const int st = st0 + u;
+            if (st < nst) {
+              if (st + PF < nst) {
+                if (u == 0) issue(std::integral_constant<int, (0 + PF) % NS>{}, std::integral_constant<int, (0 + PF) % NCB>{});
+                if (u == 1) issue(std::integral_constant<int, (1 + PF) % NS>{}, std::integral_constant<int, (1 + PF) % NCB>{});
+                if (u == 2) issue(std::integral_constant<int, (2 + PF) % NS>{}, std::integral_constant<int, (2 + PF) % NCB>{});
+                if (u == 3) issue(std::integral_constant<int, (3 + PF) % NS>{}, std::integral_constant<int, (3 + PF) % NCB>{});
+                if (u == 4) issue(std::integral_constant<int, (4 + PF) % NS>{}, std::integral_constant<int, (4 + PF) % NCB>{});
+                if (u == 5) issue(std::integral_constant<int, (5 + PF) % NS>{}, std::integral_constant<int, (5 + PF) % NCB>{});
+                if (u == 6) issue(std::integral_constant<int, (6 + PF) % NS>{}, std::integral_constant<int, (6 + PF) % NCB>{});
+                if (u == 7) issue(std::integral_constant<int, (7 + PF) % NS>{}, std::integral_constant<int, (7 + PF) % NCB>{});
+                vm_wait<PF * NWI>();
+              } else if (PF >= 2 && st + 1 < nst) {
+                vm_wait<(PF - 1) * NWI>();
+              } else {
+                vm_wait<0>();
+              }
+              raw_barrier();
+              const int cb = u % NCB;
+              const int part = (st / NCB) & (SPP - 1);
+              const int j = cur_peek(cc);
+              const int jg = j % NW, jm = j / NW;                 // owner wave, pixel of its group
+              if (jg == wave) {
+#pragma unroll
+                for (int blk = 0; blk < NB2; ++blk) {
+                  if (cb == 0) acc2[blk] = float4_t{0.f, 0.f, 0.f, 0.f};
+                  u32x4 bq[8];
+#pragma unroll
+                  for (int s = 0; s < 8; ++s)
+                    bq[s] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>((lds_u8*)(size_t)(bo2[blk][s]) + (u % NS) * SLOTB);
+                  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                  for (int s = 0; s < 8; ++s) acc2[blk] = mfma16r(a[cb * 8 + s], bq[s], acc2[blk], T{});
+                }
+                if (cb == NCB - 1) {
+                  // row jm of the 16 x 16 result: lanes of quarter jm / 4, accumulator element jm % 4
+                  const int x0j = rec_i(rx0, j) - R, y0j = rec_i(ry0, j) - R + part * PR;
+                  const int sel = jm & 3;
+#pragma unroll
+                  for (int blk = 0; blk < NB2; ++blk) {
+                    const float4_t d4 = acc2[blk];
+                    float v = sel == 0 ? d4[0] : sel == 1 ? d4[1] : sel == 2 ? d4[2] : d4[3];
+                    const int pos = 16 * blk + n16;
+                    const int dy = pos / N2, dx = pos - dy * N2;
+                    const int yy = y0j + dy, xx = x0j + dx;
+                    if (!(yy >= 0 && yy < H && xx >= 0 && xx < W)) v = 0.f;
+                    if (kg == (jm >> 2) && pos < PPS) pd[part * PPS + pos] = v * p.scale;
+                  }
+                  if (part == SPP - 1) {
+                    const float axj = rec_f(rax, j), ayj = rec_f(ray, j);
+                    const int dy = jm >> 2, dx = jm & 3;
+                    if (lane < K) {
+                      const int iy = lane / N1, ix = lane - iy * N1;
+                      const float* d = pd + iy * N2 + ix;
+                      const float top = d[0] + axj * (d[1] - d[0]);
+                      const float bot = d[N2] + axj * (d[N2 + 1] - d[N2]);
+                      const T val = from_f32<T>(top + ayj * (bot - top));
+                      if (p.out_nhwc) out[(((size_t)b * H + gpy + dy) * W + gpx + dx) * p.out_pitch + lane] = val;
+                      else out[(((size_t)b * p.out_pitch + lane) * H + gpy + dy) * W + gpx + dx] = val;
+                    }
+                  }
+                }
+              }
+              if (((st + 1) & (SPP * NCB - 1)) == 0) cur_pop(cc);
+            }
+          }
+        }
+      };
+      if (hi_share) run_patches(std::integral_constant<int, NIW2>{});
+      else run_patches(std::integral_constant<int, (n_lo > 0 ? n_lo : 0)>{});
+      return;
+    }
   }
+  (void)ok;                                                      // r >= 4: the host admits only maps every box of which fits (W <= BWMAX - 1)
 
   // =========================== streaming path ===========================
   const int nst = nrows * NCB;
@@ -346,17 +403,18 @@ __global__ __launch_bounds__(64 * NW) void local_corr_rows_kernel(LCTileParams p
     voff[k] = (uint32_t)(xs * p.f1_pitch + q * 8) * 2u;
   }
   // B fragment addresses: lane (n16, kg) reads piece s of quarter kg of staged pixel col0 + n16
-  uint32_t bo[8];
-  {
-    const int pxb = min(max(gx0 - bx0 + n16, 0), BWMAX - 1);
+  uint32_t bo[NBLK][8];
+#pragma unroll
+  for (int k = 0; k < NBLK; ++k) {
+    const int pxb = min(max(gx0 - bx0 + 16 * k + n16, 0), BWMAX - 1);
     const uint32_t base = lds0 + (uint32_t)(pxb * 512 + kg * 128), c = (uint32_t)((pxb & 7) << 4);
 #pragma unroll
-    for (int s = 0; s < 8; ++s) bo[s] = base + (c ^ (uint32_t)(s << 4));
+    for (int s = 0; s < 8; ++s) bo[k][s] = base + (c ^ (uint32_t)(s << 4));
   }
   // per accumulator row r4 (pixel 4 kg + r4 of the group): blend weights (the C^-1/2 scale folded into the y weights), the LDS
   // address of row 0 of the image column this lane produces for that pixel, and (in bytes of image rows) where its window starts
   float axv[4], ay0[4], ay1[4];
-  uint32_t wbase[4];
+  uint32_t wbase[NBLK][4];
   int wyb[4];
   constexpr int ROWB = N1 * 2;                                   // bytes per image row
   const uint32_t otb = lds0 + (uint32_t)(G::REGA + g * G::OTB);
@@ -367,29 +425,67 @@ __global__ __launch_bounds__(64 * NW) void local_corr_rows_kernel(LCTileParams p
     const float ayp = s_ay[r];
     ay1[r4] = ayp * p.scale;
     ay0[r4] = p.scale - ay1[r4];
-    const int ix = gx0 + n16 - (s_x0[r] - R);                    // window column this lane produces for that pixel
-    const bool colvalid = (unsigned)ix < (unsigned)N1;
-    wbase[r4] = otb + (uint32_t)(colvalid ? pp * PPB + ix * 2 : 16 * PPB);
+#pragma unroll
+    for (int k = 0; k < NBLK; ++k) {
+      const int ix = gx0 + 16 * k + n16 - (s_x0[r] - R);         // window column this lane produces for that pixel in block k
+      const bool colvalid = (unsigned)ix < (unsigned)N1;
+      wbase[k][r4] = otb + (uint32_t)(colvalid ? pp * PPB + ix * 2 : 16 * PPB);
+    }
     wyb[r4] = (s_y0[r] - R - ba0) * ROWB;                        // box row ya = ba0 + j is image row j - wyb / ROWB (window row + 1)
   }
-  const int xa = gx0 + n16;
-  const bool dvalid = xa >= 0 && xa <= W - 1;
-  const bool inner = __builtin_amdgcn_readfirstlane((int)(gx0 >= 0 && gx0 + 15 <= W - 1));
-  const int gs0 = ga0 - ba0, gs1 = ga1 - ba0;
-  float tprev[4] = {0.f, 0.f, 0.f, 0.f};
-  float4_t acc = {0.f, 0.f, 0.f, 0.f};
-
-  // box row ya = ba0 + j, jb = j ROWB: x-blend (DPP shift), y-blend against the previous row, store at the clamped image row
-  auto emit_row = [&](const float4_t& d4, int jb) {
+  bool dvalid[NBLK];
 #pragma unroll
-    for (int r4 = 0; r4 < 4; ++r4) {
-      float d = d4[r4];
-      if (!inner) d = dvalid ? d : 0.f;
-      const float tc = d + axv[r4] * (right_neighbour(d) - d);
-      const float v = ay0[r4] * tprev[r4] + ay1[r4] * tc;
-      tprev[r4] = tc;
-      const int rowb = min(max(jb - wyb[r4], 0), (N1 + 1) * ROWB);
-      *reinterpret_cast<__attribute__((address_space(3))) T*>((lds_u8*)(size_t)(wbase[r4] + (uint32_t)rowb)) = from_f32<T>(v);
+  for (int k = 0; k < NBLK; ++k) { const int xa = gx0 + 16 * k + n16; dvalid[k] = xa >= 0 && xa <= W - 1; }
+  const int gw = gx1 - gx0 + 1;
+  const int nblk_g = __builtin_amdgcn_readfirstlane(NBLK == 1 ? 1 : (gw + 15) >> 4);   // column blocks this group needs
+  const bool inner = __builtin_amdgcn_readfirstlane((int)(gx0 >= 0 && gx0 + 16 * nblk_g - 1 <= W - 1));
+  const bool last_col = n16 == 15;
+  const int gs0 = ga0 - ba0, gs1 = ga1 - ba0;
+  float tprev[NBLK][4];
+  float4_t acc[NBLK];
+#pragma unroll
+  for (int k = 0; k < NBLK; ++k) {
+    acc[k] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) tprev[k][r4] = 0.f;
+  }
+
+  // box row ya = ba0 + j, jb = j ROWB: x-blend (DPP: the right-hand neighbour column; across a block boundary it is lane 0 of the
+  // next block), y-blend against the previous row, store at the clamped image row
+  auto emit_row = [&](const float4_t* d, int jb) {
+    int rowb[4];
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) rowb[r4] = min(max(jb - wyb[r4], 0), (N1 + 1) * ROWB);
+    float dm[NBLK + 1][4];
+#pragma unroll
+    for (int k = 0; k < NBLK; ++k)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        float v = d[k][r4];
+        if (NBLK > 1 && k >= nblk_g) v = 0.f;
+        else if (!inner) v = dvalid[k] ? v : 0.f;
+        dm[k][r4] = v;
+      }
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) dm[NBLK][r4] = 0.f;
+#pragma unroll
+    for (int k = 0; k < NBLK; ++k) {
+      if (NBLK > 1 && k >= nblk_g) break;
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const float dcur = dm[k][r4];
+        float rgt;
+        if (NBLK == 1) {
+          rgt = right_neighbour(dcur);
+        } else {
+          const float a0 = rot_left(dcur), a1 = rot_left(dm[k + 1][r4]);
+          rgt = last_col ? a1 : a0;
+        }
+        const float tc = dcur + axv[r4] * (rgt - dcur);
+        const float v = ay0[r4] * tprev[k][r4] + ay1[r4] * tc;
+        tprev[k][r4] = tc;
+        *reinterpret_cast<__attribute__((address_space(3))) T*>((lds_u8*)(size_t)(wbase[k][r4] + (uint32_t)rowb[r4])) = from_f32<T>(v);
+      }
     }
   };
 
@@ -431,29 +527,54 @@ __global__ __launch_bounds__(64 * NW) void local_corr_rows_kernel(LCTileParams p
           const int cb = u % NCB;
           const int jr = NCB == 1 ? st : st >> 1;
           if (jr >= gs0 && jr <= gs1) {
-            if (cb == 0) acc = float4_t{0.f, 0.f, 0.f, 0.f};
-            u32x4 bq[8];
+            // B fragments of two blocks at a time: sixteen reads in flight before the first MFMA waits
 #pragma unroll
-            for (int s = 0; s < 8; ++s)
-              bq[s] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>((lds_u8*)(size_t)(bo[s]) + (u % NS) * SLOTB);
-            __builtin_amdgcn_sched_barrier(0);                   // all eight reads in flight before the first MFMA waits
+            for (int k0 = 0; k0 < NBLK; k0 += 2) {
+              if (NBLK > 1 && k0 >= nblk_g) break;
+              constexpr int KP = NBLK > 1 ? 2 : 1;
+              u32x4 bq[KP][8];
 #pragma unroll
-            for (int s = 0; s < 8; ++s) acc = mfma16r(a[cb * 8 + s], bq[s], acc, T{});
-            if (cb == NCB - 1) {
-              emit_row(acc, jr * ROWB);
+              for (int kk = 0; kk < KP; ++kk) {
+                const int k = k0 + kk < NBLK ? k0 + kk : NBLK - 1;
+                if (k0 + kk >= NBLK || (NBLK > 1 && k >= nblk_g)) continue;
+#pragma unroll
+                for (int s = 0; s < 8; ++s)
+                  bq[kk][s] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>((lds_u8*)(size_t)(bo[k][s]) + (u % NS) * SLOTB);
+              }
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int kk = 0; kk < KP; ++kk) {
+                const int k = k0 + kk < NBLK ? k0 + kk : NBLK - 1;
+                if (k0 + kk >= NBLK || (NBLK > 1 && k >= nblk_g)) continue;
+                if (cb == 0) acc[k] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 8; ++s) acc[k] = mfma16r(a[cb * 8 + s], bq[kk][s], acc[k], T{});
+              }
             }
+            if (cb == NCB - 1) emit_row(acc, jr * ROWB);
           }
         }
       }
     }
   };
-  switch (n_w) {
-    case 0: run(std::integral_constant<int, 0>{}); break;
-    case 1: run(std::integral_constant<int, 1>{}); break;
-    case 2: if constexpr (NIW >= 2) run(std::integral_constant<int, 2>{}); break;
-    default: if constexpr (NIW >= 3) run(std::integral_constant<int, 3>{}); break;
+  if constexpr (NIW <= 3) {
+    switch (n_w) {
+      case 0: run(std::integral_constant<int, 0>{}); break;
+      case 1: run(std::integral_constant<int, 1>{}); break;
+      case 2: if constexpr (NIW >= 2) run(std::integral_constant<int, 2>{}); break;
+      default: if constexpr (NIW >= 3) run(std::integral_constant<int, 3>{}); break;
+    }
+  } else {
+    // wide boxes: two instantiations; a wave issues up to one DMA more than its share (the surplus re-reads the box's last pixels: L1 hits)
+    if (n_w * 2 <= NIW) run(std::integral_constant<int, (NIW + 1) / 2>{});
+    else run(std::integral_constant<int, NIW>{});
   }
-  if (gvirt) emit_row(float4_t{0.f, 0.f, 0.f, 0.f}, (H - ba0) * ROWB);   // the virtual row below the image
+  if (gvirt) {                                                   // the virtual row below the image
+    float4_t z[NBLK];
+#pragma unroll
+    for (int k = 0; k < NBLK; ++k) z[k] = float4_t{0.f, 0.f, 0.f, 0.f};
+    emit_row(z, (H - ba0) * ROWB);
+  }
 
   // ---- write the group's output image: wave-private, no barrier; 32-bit element offsets from a wave-uniform base ----
   const T* ot = reinterpret_cast<const T*>(ot_all + g * G::OTB);
@@ -492,29 +613,36 @@ int launch_rows(LCTileParams p, hipStream_t stream) {
 }
 
 template <typename T, int R>
-int launch_rows_c(const LCTileParams& p, int tile_h, hipStream_t stream) {
-  if (p.C == 256) return tile_h == 16 ? launch_rows<T, R, 1, 8>(p, stream) : launch_rows<T, R, 1, 4>(p, stream);
-  if (p.C == 512) return tile_h == 16 ? launch_rows<T, R, 2, 8>(p, stream) : launch_rows<T, R, 2, 4>(p, stream);
+int launch_rows_c(const LCTileParams& p, hipStream_t stream) {
+  if (p.C == 256) return launch_rows<T, R, 1, 4>(p, stream);
+  if (p.C == 512) return launch_rows<T, R, 2, 4>(p, stream);
   set_error("local_corr_rows: C = %d (supported: 256, 512)", p.C);
   return ROMA_E_UNSUPPORTED;
 }
 
 }  // namespace
 
-bool local_corr_rows_supports(int C) { return C == 256 || C == 512; }
+// r <= 3: any map; r = 7 (the scale-16 level; the only r >= 4 instantiated): maps small enough that a tile's box may be the whole map
+bool local_corr_rows_supports(int C, int r, int H, int W) {
+  if (!(C == 256 || C == 512)) return false;
+  if (r <= 3) return true;
+  return r == 7 && W <= RowsGeom<7, 4>::BWMAX - 1 && H <= RowsGeom<7, 4>::MAXROWS;
+}
 
-int local_corr_rows(const LCTileParams& p, int r, int dtype, int tile_h, hipStream_t stream) {
+int local_corr_rows(const LCTileParams& p, int r, int dtype, hipStream_t stream) {
   if (dtype == ROMA_F16) {
     switch (r) {
-      case 1: return launch_rows_c<half_t, 1>(p, tile_h, stream);
-      case 2: return launch_rows_c<half_t, 2>(p, tile_h, stream);
-      case 3: return launch_rows_c<half_t, 3>(p, tile_h, stream);
+      case 1: return launch_rows_c<half_t, 1>(p, stream);
+      case 2: return launch_rows_c<half_t, 2>(p, stream);
+      case 3: return launch_rows_c<half_t, 3>(p, stream);
+      case 7: return launch_rows_c<half_t, 7>(p, stream);
     }
   } else if (dtype == ROMA_BF16) {
     switch (r) {
-      case 1: return launch_rows_c<bf16_t, 1>(p, tile_h, stream);
-      case 2: return launch_rows_c<bf16_t, 2>(p, tile_h, stream);
-      case 3: return launch_rows_c<bf16_t, 3>(p, tile_h, stream);
+      case 1: return launch_rows_c<bf16_t, 1>(p, stream);
+      case 2: return launch_rows_c<bf16_t, 2>(p, stream);
+      case 3: return launch_rows_c<bf16_t, 3>(p, stream);
+      case 7: return launch_rows_c<bf16_t, 7>(p, stream);
     }
   }
   set_error("local_corr_rows: unsupported r=%d dtype=%d", r, dtype);

@@ -134,7 +134,7 @@ def local_correlation(feature0, feature1, local_radius, padding_mode="zeros", fl
     """romatch/utils/local_correlation.py:4-48.  Returns (B,(2r+1)^2,h,w) in feature0's dtype and memory format
     (or fills `out`, e.g. a channel slice of the refiner's channels-last concat buffer).  batch_shift: feature0[b] meets
     feature1[(b + batch_shift) % B] (forward_symmetric passes the same map twice with batch_shift = B/2).  variant: "auto" or
-    one of "tile8x4" / "tile8x8" / "ring" — the three kernels for 16-bit channels-last inputs with r <= 3 (roma_hip.h)."""
+    one of "tile8x4" / "tile8x8" / "rows8" — the kernels for 16-bit channels-last inputs (roma_hip.h)."""
     if padding_mode != "zeros" or sample_mode != "bilinear":
         raise NotImplementedError("only padding_mode='zeros', sample_mode='bilinear' (the modes RoMa uses)")
     _need_gpu(feature0, feature1, flow, out)

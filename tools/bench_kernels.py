@@ -34,7 +34,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=1)
     ap.add_argument("--dtype", default="f16")
     ap.add_argument("--flow", default="coherent")
-    ap.add_argument("--variant", default="auto", help="local_corr kernel: auto | tile8x4 | tile8x8 | rows8 | rows16")
+    ap.add_argument("--variant", default="auto", help="local_corr kernel: auto | tile8x4 | tile8x8 | rows8")
     args = ap.parse_args()
     dt = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[args.dtype]
     es = 4 if dt == torch.float32 else 2

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """local_correlation: every kernel variant at the five 560->864 call shapes, coherent flow, fp16 channels-last.
-   python tools/lc_bench.py [--pairs 1 16] [--variants auto tile8x8 rows8 rows16] [--flow coherent]"""
+   python tools/lc_bench.py [--pairs 1 16] [--variants auto tile8x8 rows8] [--flow coherent]"""
 import argparse, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,7 +9,7 @@ from tests.golden import recipes as R
 SH = [("L16", 512, 40, 7), ("L8", 512, 70, 3), ("L4", 256, 140, 2), ("U8", 512, 108, 3), ("U4", 256, 216, 2)]
 ap = argparse.ArgumentParser()
 ap.add_argument("--pairs", type=int, nargs="+", default=[1, 16])
-ap.add_argument("--variants", nargs="+", default=["auto", "tile8x4", "tile8x8", "rows8", "rows16"])
+ap.add_argument("--variants", nargs="+", default=["auto", "tile8x4", "tile8x8", "rows8"])
 ap.add_argument("--flow", default="coherent")
 ap.add_argument("--dtype", default="f16")
 ap.add_argument("--iters", type=int, default=30)

@@ -12,7 +12,7 @@ ap.add_argument("--pairs", type=int, default=1)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--flow", default="coherent")
 ap.add_argument("--dtype", default="f16")
-ap.add_argument("--variant", default="auto", choices=["auto", "tile8x4", "tile8x8", "rows8", "rows16"])
+ap.add_argument("--variant", default="auto", choices=["auto", "tile8x4", "tile8x8", "rows8"])
 a = ap.parse_args()
 C, h, r = SH[a.shape]
 dt = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[a.dtype]
