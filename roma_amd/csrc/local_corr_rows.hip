@@ -195,194 +195,137 @@ __global__ __launch_bounds__(64 * NW) void local_corr_rows_kernel(LCTileParams p
   if constexpr (G::kPatchPath) {
     if (!__builtin_amdgcn_readfirstlane((int)ok)) {
       // =========================== incoherent tile: every pixel gathers its own (2r+2)^2 patch ===========================
-      // Same ring, same whole-row DMAs, same A registers as the streaming path; a stage is PR rows of ONE pixel's patch (16-18
-      // positions x 256 channels).  All waves stage, the wave that owns the pixel's group multiplies (the 16 x 16 MFMA computes the
-      // stage's positions against all 16 pixels of the group; the pixel's own row is kept), and when the pixel's last stage is done
-      // that wave blends the patch in a 256-byte LDS image of its own and stores the K outputs.  Pixels outside the image or whose
-      // window misses the map are not staged at all (their outputs are zero).  The 32-channel-chunk kernels gather 64-byte pieces
-      // (10-12 TB/s ceiling, tools/stage_micro.hip); whole 512-byte rows reach 14-16.
+      // WAVE-PRIVATE streaming: wave g walks the 16 pixels of its own group, one after the other; a stage is ONE ROW of the pixel's
+      // patch (2r+2 positions x 256 channels, every position a whole 512-byte request) DMA'd by this wave alone into its own 2-3
+      // slot ring, so there is no workgroup barrier anywhere — the four waves drift apart freely and a wave's MFMAs overlap the
+      // other waves' DMA waits.  The 16 x 16 MFMA multiplies the row's positions with all 16 pixels of the group (A is already in
+      // registers); the pixel's own result row goes into a 256-byte LDS patch image, and after the patch's last row the wave blends
+      // and stores the K outputs.  Pixels outside the image or whose window misses the map are not staged (outputs zero).
+      // (The 32-channel-chunk kernels gather 64-byte pieces, 10-12 TB/s at best — tools/stage_micro.hip; a first version of this
+      // path with workgroup-wide stages and one owner wave per stage was barrier-bound and slower than they are.)
       constexpr int N2 = 2 * R + 2;
-      constexpr int PR = R == 1 ? 4 : R == 2 ? 3 : 2;             // patch rows per stage
-      constexpr int PPS = PR * N2;                                // positions per stage: 16 / 18 / 16
-      constexpr int SPP = N2 / PR;                                // stages per pixel and channel block: 1 / 2 / 4
-      constexpr int NB2 = (PPS + 15) / 16;                        // MFMA column blocks per stage
-      constexpr int NIT2 = (PPS + 1) / 2;                         // DMA wave-instructions per stage
-      constexpr int NIW2 = (NIT2 + NW - 1) / NW;
-      constexpr int NREG = NPIX / 64;                             // pixel records per lane (1 at 8x8 tiles, 2 at 8x16)
-      static_assert(PPS <= BWMAX && N2 % PR == 0 && K <= 64, "patch stage geometry");
-      // every wave keeps every pixel's target: record j = m NW + g (so that consecutive records belong to different waves)
-      int rx0[NREG], ry0[NREG];
-      float rax[NREG], ray[NREG];
-      unsigned long long act[NREG];
-#pragma unroll
-      for (int q = 0; q < NREG; ++q) {
-        const int j = q * 64 + lane, gg = j % NW, mm = j / NW, r = gg * 16 + mm;
-        rx0[q] = s_x0[r]; ry0[q] = s_y0[r]; rax[q] = s_ax[r]; ray[q] = s_ay[r];
-        const int py = ty0 + (gg >> 1) * 4 + (mm >> 2), px = tx0 + (gg & 1) * 4 + (mm & 3);
-        const bool hit = py < H && px < W && max(rx0[q] - R, 0) <= min(rx0[q] + R + 1, W - 1) && max(ry0[q] - R, 0) <= min(ry0[q] + R + 1, H - 1);
-        act[q] = __ballot(hit);
+      constexpr int NIP = N2 / 2;                                 // DMA wave-instructions per patch row (two positions each)
+      constexpr int SLOTW = N2 * 512;                             // one patch row of one channel block
+      constexpr int NSW = R <= 2 ? 3 : 2;                         // wave-private ring slots; NSW - 1 rows in flight beside the one in use
+      constexpr int PFW = NSW - 1;
+      constexpr int UNRW = (NSW % NCB == 0) ? NSW : NSW * NCB;    // unroll: slot and channel block compile-time
+      static_assert(NSW * SLOTW * NW <= G::REGA && K <= 64 && G::OTB >= N2 * N2 * 4, "patch path geometry");
+      // this wave's pixels: record m = pixel of the group (lane m holds it; lanes >= 16 replicate)
+      const int mrec = lane & 15;
+      const int qx0 = s_x0[g * 16 + mrec], qy0 = s_y0[g * 16 + mrec];
+      const float qax = s_ax[g * 16 + mrec], qay = s_ay[g * 16 + mrec];
+      const bool hit = gpy + (mrec >> 2) < H && gpx + (mrec & 3) < W && max(qx0 - R, 0) <= min(qx0 + R + 1, W - 1) &&
+                       max(qy0 - R, 0) <= min(qy0 + R + 1, H - 1);
+      const uint32_t act = (uint32_t)(__ballot(hit) & 0xffffull);
+      T* ob = p.out_nhwc ? out + (((size_t)b * H + gpy) * W + gpx) * p.out_pitch : out + ((size_t)b * p.out_pitch * H + gpy) * W + gpx;
+      const uint32_t plane = (uint32_t)(H * W);
+      auto out_off = [&](int mm, int kk) -> uint32_t {
+        const int dy = mm >> 2, dx = mm & 3;
+        return p.out_nhwc ? (uint32_t)((dy * W + dx) * p.out_pitch + kk) : (uint32_t)kk * plane + (uint32_t)(dy * W + dx);
+      };
+      for (int mm = 0; mm < 16; ++mm) {                           // zeros for pixels inside the image that gather nothing
+        if (((act >> mm) & 1u) || gpy + (mm >> 2) >= H || gpx + (mm & 3) >= W) continue;
+        if (lane < K) ob[out_off(mm, lane)] = from_f32<T>(0.f);
       }
-      // zeros for this wave's pixels that are inside the image but gather nothing
-      {
-        T* ob = p.out_nhwc ? out + (((size_t)b * H + gpy) * W + gpx) * p.out_pitch : out + ((size_t)b * p.out_pitch * H + gpy) * W + gpx;
-        const uint32_t plane = (uint32_t)(H * W);
-        for (int mm = 0; mm < 16; ++mm) {
-          const int j = mm * NW + g;
-          const bool on = (act[j >> 6] >> (j & 63)) & 1ull;
-          const int dy = mm >> 2, dx = mm & 3;
-          if (on || gpy + dy >= H || gpx + dx >= W) continue;   // wave-uniform
-          if (lane < K) ob[p.out_nhwc ? (uint32_t)((dy * W + dx) * p.out_pitch + lane) : (uint32_t)lane * plane + (uint32_t)(dy * W + dx)] = from_f32<T>(0.f);
-        }
-      }
-      int npx = 0;
+      const int nstw = __builtin_popcount(act) * N2 * NCB;
+      // DMA plan of one patch row: instruction k covers positions 2k, 2k + 1
+      uint32_t coff[NIP], vconst[NIP];
+      int dxk[NIP];
 #pragma unroll
-      for (int q = 0; q < NREG; ++q) npx += __builtin_popcountll(act[q]);
-      npx = __builtin_amdgcn_readfirstlane(npx);
-      const int nst = npx * SPP * NCB;
-      // DMA plan: instruction ii = k NW + wave covers positions 2 ii, 2 ii + 1 of the stage
-      int dyk[NIW2], dxk[NIW2];
-      uint32_t coff[NIW2];
-#pragma unroll
-      for (int k = 0; k < NIW2; ++k) {
-        const int P = (k * NW + wave) * 64 + lane;
-        const int pos = P >> 5, qp = P & 31;
-        const int posc = min(pos, PPS - 1);
-        dyk[k] = posc / N2; dxk[k] = posc - dyk[k] * N2;
+      for (int k = 0; k < NIP; ++k) {
+        const int pos = 2 * k + (lane >> 5), qp = lane & 31;
+        dxk[k] = pos;
         coff[k] = (uint32_t)(((qp & 24) | ((qp ^ pos) & 7)) * 16);
+        vconst[k] = (uint32_t)(pos * p.f1_pitch) * 2u + coff[k];
       }
-      constexpr int n_lo = NIW2 - 1;
-      const bool hi_share = wave < NIT2 - n_lo * NW;             // waves that issue NIW2 instructions per stage, the others one fewer
-      // B fragment addresses: position 16 blk + n16 of the stage
-      uint32_t bo2[NB2][8];
+      const uint32_t ring0 = lds0 + (uint32_t)(wave * NSW * SLOTW);
+      uint32_t bo2[8];
+      {
+        const int pos = min(n16, N2 - 1);
+        const uint32_t base = ring0 + (uint32_t)(pos * 512 + kg * 128), c = (uint32_t)((pos & 7) << 4);
 #pragma unroll
-      for (int blk = 0; blk < NB2; ++blk) {
-        const int pos = min(16 * blk + n16, BWMAX - 1);
-        const uint32_t base = lds0 + (uint32_t)(pos * 512 + kg * 128), c = (uint32_t)((pos & 7) << 4);
-#pragma unroll
-        for (int s = 0; s < 8; ++s) bo2[blk][s] = base + (c ^ (uint32_t)(s << 4));
+        for (int s = 0; s < 8; ++s) bo2[s] = base + (c ^ (uint32_t)(s << 4));
       }
       float* pd = reinterpret_cast<float*>(ot_all + g * G::OTB);  // this wave's patch image: Q products of the pixel in hand
-      static_assert(G::OTB >= (int)((2 * R + 2) * (2 * R + 2) * 4), "patch image fits the group's output image");
 
-      // the n-th active pixel record, in record order: a cursor over the activity masks, advanced by the issuing side and (PF stages
-      // later) by the computing side
-      struct Cursor { unsigned long long m[NREG]; int q; };
-      auto cur_init = [&](Cursor& c) {
+      // issue side and compute side each walk (pixel, patch row); the pixel cursor is a bit mask
+      uint32_t mi = act, mc = act;
+      int rowi = 0, rowc = 0;
+      auto issue = [&](auto slot_c, auto cb_c) {
+        constexpr int SLOT = decltype(slot_c)::value, CB = decltype(cb_c)::value;
+        const int mm = __builtin_ctz(mi);
+        const int x0j = __builtin_amdgcn_readlane(qx0, mm) - R, yj = __builtin_amdgcn_readlane(qy0, mm) - R + rowi;
+        const uint32_t dst = ring0 + (uint32_t)(SLOT * SLOTW);
+        if (x0j >= 0 && x0j + N2 - 1 <= W - 1 && yj >= 0 && yj <= H - 1) {                  // wave-uniform: the common case
+          const T* sb = f1 + CB * 256 + (size_t)(yj * W + x0j) * p.f1_pitch;                 // the row's first position rides on the scalar base
 #pragma unroll
-        for (int q = 0; q < NREG; ++q) c.m[q] = act[q];
-        c.q = 0;
-      };
-      auto cur_peek = [&](Cursor& c) -> int {                     // record index of the next active pixel (there is one)
-        if (NREG > 1 && c.m[0] == 0 && c.q == 0) c.q = 1;
-        const unsigned long long mk = NREG > 1 && c.q == 1 ? c.m[NREG - 1] : c.m[0];
-        return c.q * 64 + __builtin_ctzll(mk);
-      };
-      auto cur_pop = [&](Cursor& c) {
-        if (NREG > 1 && c.q == 1) c.m[NREG - 1] &= c.m[NREG - 1] - 1; else c.m[0] &= c.m[0] - 1;
-      };
-      auto rec_i = [&](const int* v, int j) -> int {
-        return NREG > 1 && j >= 64 ? __builtin_amdgcn_readlane(v[NREG - 1], j - 64) : __builtin_amdgcn_readlane(v[0], j & 63);
-      };
-      auto rec_f = [&](const float* v, int j) -> float {
-        return __builtin_bit_cast(float, NREG > 1 && j >= 64 ? __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[NREG - 1]), j - 64)
-                                                            : __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[0]), j & 63));
-      };
-
-      auto run_patches = [&](auto nwi_c) {
-        constexpr int NWI = decltype(nwi_c)::value;
-        const uint32_t dst0 = lds0 + (uint32_t)(wave * 1024);
-        Cursor ci, cc;
-        cur_init(ci); cur_init(cc);
-        int ist = 0;                                              // stages issued so far
-        auto issue = [&](auto slot_c, auto cb_c) {
-          constexpr int SLOT = decltype(slot_c)::value, CB = decltype(cb_c)::value;
-          const int j = cur_peek(ci);
-          const int part = (ist / NCB) & (SPP - 1);
-          const int x0j = rec_i(rx0, j) - R, y0j = rec_i(ry0, j) - R + part * PR;
+          for (int k = 0; k < NIP; ++k) dma_row(sb, vconst[k], dst + (uint32_t)(k * 1024));
+        } else {
+          const int yy = min(max(yj, 0), H - 1);
 #pragma unroll
-          for (int k = 0; k < NWI; ++k) {
-            const int yy = min(max(y0j + dyk[k], 0), H - 1), xx = min(max(x0j + dxk[k], 0), W - 1);
-            dma_row(f1 + CB * 256, (uint32_t)((yy * W + xx) * p.f1_pitch) * 2u + coff[k], dst0 + (uint32_t)(SLOT * SLOTB + k * NW * 1024));
+          for (int k = 0; k < NIP; ++k) {
+            const int xx = min(max(x0j + dxk[k], 0), W - 1);
+            dma_row(f1 + CB * 256, (uint32_t)((yy * W + xx) * p.f1_pitch) * 2u + coff[k], dst + (uint32_t)(k * 1024));
           }
-          ++ist;
-          if ((ist & (SPP * NCB - 1)) == 0) cur_pop(ci);
-        };
-        float4_t acc2[NB2];
-        if (PF >= 1 && nst > 0) issue(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-        if (PF >= 2 && nst > 1) issue(std::integral_constant<int, 1 % NS>{}, std::integral_constant<int, 1 % NCB>{});
-        for (int st0 = 0; st0 < nst; st0 += UNR) {
+        }
+        if (CB == NCB - 1 && ++rowi == N2) { rowi = 0; mi &= mi - 1; }
+      };
+      float4_t acc2 = {0.f, 0.f, 0.f, 0.f};
+      if (nstw > 0) issue(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+      if (PFW >= 2 && nstw > 1) issue(std::integral_constant<int, 1 % NSW>{}, std::integral_constant<int, 1 % NCB>{});
+      for (int st0 = 0; st0 < nstw; st0 += UNRW) {
 #pragma unroll
-          for (int u = 0; u < UNR; ++u) {
-            const int st = st0 + u;
-            if (st < nst) {
-              if (st + PF < nst) {
-                if (u == 0) issue(std::integral_constant<int, (0 + PF) % NS>{}, std::integral_constant<int, (0 + PF) % NCB>{});
-                if (u == 1) issue(std::integral_constant<int, (1 + PF) % NS>{}, std::integral_constant<int, (1 + PF) % NCB>{});
-                if (u == 2) issue(std::integral_constant<int, (2 + PF) % NS>{}, std::integral_constant<int, (2 + PF) % NCB>{});
-                if (u == 3) issue(std::integral_constant<int, (3 + PF) % NS>{}, std::integral_constant<int, (3 + PF) % NCB>{});
-                if (u == 4) issue(std::integral_constant<int, (4 + PF) % NS>{}, std::integral_constant<int, (4 + PF) % NCB>{});
-                if (u == 5) issue(std::integral_constant<int, (5 + PF) % NS>{}, std::integral_constant<int, (5 + PF) % NCB>{});
-                if (u == 6) issue(std::integral_constant<int, (6 + PF) % NS>{}, std::integral_constant<int, (6 + PF) % NCB>{});
-                if (u == 7) issue(std::integral_constant<int, (7 + PF) % NS>{}, std::integral_constant<int, (7 + PF) % NCB>{});
-                vm_wait<PF * NWI>();
-              } else if (PF >= 2 && st + 1 < nst) {
-                vm_wait<(PF - 1) * NWI>();
-              } else {
-                vm_wait<0>();
-              }
-              raw_barrier();
-              const int cb = u % NCB;
-              const int part = (st / NCB) & (SPP - 1);
-              const int j = cur_peek(cc);
-              const int jg = j % NW, jm = j / NW;                 // owner wave, pixel of its group
-              if (jg == wave) {
+        for (int u = 0; u < UNRW; ++u) {
+          const int st = st0 + u;
+          if (st < nstw) {
+            if (st + PFW < nstw) {
+              if (u == 0) issue(std::integral_constant<int, (0 + PFW) % NSW>{}, std::integral_constant<int, (0 + PFW) % NCB>{});
+              if (u == 1) issue(std::integral_constant<int, (1 + PFW) % NSW>{}, std::integral_constant<int, (1 + PFW) % NCB>{});
+              if (u == 2) issue(std::integral_constant<int, (2 + PFW) % NSW>{}, std::integral_constant<int, (2 + PFW) % NCB>{});
+              if (u == 3) issue(std::integral_constant<int, (3 + PFW) % NSW>{}, std::integral_constant<int, (3 + PFW) % NCB>{});
+              if (u == 4) issue(std::integral_constant<int, (4 + PFW) % NSW>{}, std::integral_constant<int, (4 + PFW) % NCB>{});
+              if (u == 5) issue(std::integral_constant<int, (5 + PFW) % NSW>{}, std::integral_constant<int, (5 + PFW) % NCB>{});
+              vm_wait<PFW * NIP>();
+            } else if (PFW >= 2 && st + 1 < nstw) {
+              vm_wait<(PFW - 1) * NIP>();
+            } else {
+              vm_wait<0>();
+            }
+            const int cb = u % NCB;
+            if (cb == 0) acc2 = float4_t{0.f, 0.f, 0.f, 0.f};
+            u32x4 bq[8];
 #pragma unroll
-                for (int blk = 0; blk < NB2; ++blk) {
-                  if (cb == 0) acc2[blk] = float4_t{0.f, 0.f, 0.f, 0.f};
-                  u32x4 bq[8];
+            for (int s = 0; s < 8; ++s)
+              bq[s] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>((lds_u8*)(size_t)(bo2[s]) + (u % NSW) * SLOTW);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                  for (int s = 0; s < 8; ++s)
-                    bq[s] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>((lds_u8*)(size_t)(bo2[blk][s]) + (u % NS) * SLOTB);
-                  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                  for (int s = 0; s < 8; ++s) acc2[blk] = mfma16r(a[cb * 8 + s], bq[s], acc2[blk], T{});
-                }
-                if (cb == NCB - 1) {
-                  // row jm of the 16 x 16 result: lanes of quarter jm / 4, accumulator element jm % 4
-                  const int x0j = rec_i(rx0, j) - R, y0j = rec_i(ry0, j) - R + part * PR;
-                  const int sel = jm & 3;
-#pragma unroll
-                  for (int blk = 0; blk < NB2; ++blk) {
-                    const float4_t d4 = acc2[blk];
-                    float v = sel == 0 ? d4[0] : sel == 1 ? d4[1] : sel == 2 ? d4[2] : d4[3];
-                    const int pos = 16 * blk + n16;
-                    const int dy = pos / N2, dx = pos - dy * N2;
-                    const int yy = y0j + dy, xx = x0j + dx;
-                    if (!(yy >= 0 && yy < H && xx >= 0 && xx < W)) v = 0.f;
-                    if (kg == (jm >> 2) && pos < PPS) pd[part * PPS + pos] = v * p.scale;
-                  }
-                  if (part == SPP - 1) {
-                    const float axj = rec_f(rax, j), ayj = rec_f(ray, j);
-                    const int dy = jm >> 2, dx = jm & 3;
-                    if (lane < K) {
-                      const int iy = lane / N1, ix = lane - iy * N1;
-                      const float* d = pd + iy * N2 + ix;
-                      const float top = d[0] + axj * (d[1] - d[0]);
-                      const float bot = d[N2] + axj * (d[N2 + 1] - d[N2]);
-                      const T val = from_f32<T>(top + ayj * (bot - top));
-                      if (p.out_nhwc) out[(((size_t)b * H + gpy + dy) * W + gpx + dx) * p.out_pitch + lane] = val;
-                      else out[(((size_t)b * p.out_pitch + lane) * H + gpy + dy) * W + gpx + dx] = val;
-                    }
-                  }
+            for (int s = 0; s < 8; ++s) acc2 = mfma16r(a[cb * 8 + s], bq[s], acc2, T{});
+            if (cb == NCB - 1) {
+              // result row jm (the pixel in hand): lanes of quarter jm / 4, accumulator element jm % 4; column n16 = position in the row
+              const int jm = __builtin_ctz(mc);
+              const int x0j = __builtin_amdgcn_readlane(qx0, jm) - R, yj = __builtin_amdgcn_readlane(qy0, jm) - R + rowc;
+              const int sel = jm & 3;
+              float v = sel == 0 ? acc2[0] : sel == 1 ? acc2[1] : sel == 2 ? acc2[2] : acc2[3];
+              const int xx = x0j + n16;
+              if (!(yj >= 0 && yj < H && xx >= 0 && xx < W)) v = 0.f;
+              if (kg == (jm >> 2) && n16 < N2) pd[rowc * N2 + n16] = v * p.scale;
+              if (++rowc == N2) {
+                rowc = 0;
+                mc &= mc - 1;
+                const float axj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qax), jm));
+                const float ayj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qay), jm));
+                if (lane < K) {
+                  const int iy = lane / N1, ix = lane - iy * N1;
+                  const float* d = pd + iy * N2 + ix;
+                  const float top = d[0] + axj * (d[1] - d[0]);
+                  const float bot = d[N2] + axj * (d[N2 + 1] - d[N2]);
+                  ob[out_off(jm, lane)] = from_f32<T>(top + ayj * (bot - top));
                 }
               }
-              if (((st + 1) & (SPP * NCB - 1)) == 0) cur_pop(cc);
             }
           }
         }
-      };
-      if (hi_share) run_patches(std::integral_constant<int, NIW2>{});
-      else run_patches(std::integral_constant<int, (n_lo > 0 ? n_lo : 0)>{});
+      }
       return;
     }
   }
