@@ -85,9 +85,21 @@ class VGG19(nn.Module):
         return feats
 
 
+def enable_miopen_find():
+    """MIOpen picks its convolution solver per shape either from a heuristic (torch's default: for most of the VGG19 3x3 layers at
+    560 / 864 that is im2col + GEMM: 22 `Im2d2Col_v2` launches per match, 0.9 ms) or by timing every applicable solver once per
+    (process, shape) — torch.backends.cudnn.benchmark.  Measured on MI355X: VGG19 560 + 864 passes 4.82 -> 4.18 ms, the whole match
+    20.18 -> 19.77 ms, for ~30 s of one-time solver search in a fresh process (gpurun_out: tools/scratch/find_test.py).  On unless
+    ROMA_MIOPEN_FIND=0."""
+    import os
+    if os.environ.get("ROMA_MIOPEN_FIND", "1") != "0":
+        torch.backends.cudnn.benchmark = True
+
+
 class CNNandDinov2(nn.Module):
     def __init__(self, dinov2: Optional[DinoViT] = None, amp_dtype=torch.float16):
         super().__init__()
+        enable_miopen_find()
         self.cnn = VGG19()
         self.amp_dtype = amp_dtype
         self.dinov2_vitl14 = [dinov2 if dinov2 is not None else DinoViT()]   # outside the module tree (encoders.py:104)
