@@ -189,6 +189,11 @@ int roma_bias_relu_nchw(void* x, const void* bias, int B, int C, int HW, int dty
  * H and W even. */
 int roma_bias_relu_pool2_nchw(void* x, const void* bias, void* pooled, int B, int C, int H, int W, int dtype, void* stream);
 
+/* The same two epilogues on channels-last maps (x: npix x C rows, C a multiple of 8 (16-bit) / 4 (fp32), in place; pooled:
+ * (B, H/2, W/2, C)): the layout the VGG19 stack runs in (encoders.py:68-78). */
+int roma_bias_relu_nhwc(void* x, const void* bias, long npix, int C, int dtype, void* stream);
+int roma_bias_relu_pool2_nhwc(void* x, const void* bias, void* pooled, int B, int C, int H, int W, int dtype, void* stream);
+
 /* ConvRefiner block front half — matcher.py:77-103 (create_block: depthwise 5x5 conv, BatchNorm(eval), ReLU),
  * fused, channels-last.  BN is folded by the caller: y = relu(dwconv(x, w) * scale + shift).
  *   x,y: (B,H,W,pitch) `dtype`; w: (25, C) fp32 tap-major; scale, shift: (C) fp32. */

@@ -44,6 +44,8 @@ SIGNATURES = {
     "roma_normalize_u8": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "roma_bias_relu_nchw": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "roma_bias_relu_pool2_nchw": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "roma_bias_relu_nhwc": [c_void_p, c_void_p, c_long, c_int, c_int, c_void_p],
+    "roma_bias_relu_pool2_nhwc": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "roma_pointwise_mfma": [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "roma_refiner_block": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                            c_int, c_int, c_void_p],

@@ -85,10 +85,98 @@ __global__ __launch_bounds__(256) void bias_relu_pool_kernel(T* __restrict__ x, 
   }
 }
 
+// ---- channels-last (NHWC) variants: the layout the VGG19 stack runs in since round 3 (with MIOpen's solver search on, the CK
+// NHWC implicit-GEMM kernels are the fastest 3x3 solvers on gfx950 — and on planar activations MIOpen wraps them in layout
+// transposes: 1.3 ms of `batched_transpose` per match).  One thread = one 16-byte channel packet of one pixel.
+template <typename T>
+__global__ __launch_bounds__(256) void bias_relu_nhwc_kernel(T* __restrict__ x, const T* __restrict__ bias, long npack, int cpack) {
+  constexpr int E = ElemTraits<T>::kPer16B;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < npack; i += (long)gridDim.x * 256) {
+    float f[E], bb[E];
+    unpack16<T>(reinterpret_cast<const u32x4*>(x)[i], f);
+    unpack16<T>(reinterpret_cast<const u32x4*>(bias)[i % cpack], bb);
+#pragma unroll
+    for (int e = 0; e < E; ++e) f[e] = fmaxf(f[e] + bb[e], 0.f);
+    reinterpret_cast<u32x4*>(x)[i] = pack16<T>(f);
+  }
+}
+
+// bias + ReLU in place and the 2x2 / stride-2 max of the result: one thread = one channel packet of one POOLED pixel
+template <typename T>
+__global__ __launch_bounds__(256) void bias_relu_pool_nhwc_kernel(T* __restrict__ x, const T* __restrict__ bias, T* __restrict__ pooled,
+                                                                 int B, int H, int W, int cpack) {
+  constexpr int E = ElemTraits<T>::kPer16B;
+  const int Ho = H / 2, Wo = W / 2;
+  const long n = (long)B * Ho * Wo * cpack;
+  u32x4* xv = reinterpret_cast<u32x4*>(x);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int cp = (int)(i % cpack);
+    long r = i / cpack;
+    const int xo = (int)(r % Wo);
+    r /= Wo;
+    const int yo = (int)(r % Ho), b = (int)(r / Ho);
+    float bb[E], m[E];
+    unpack16<T>(reinterpret_cast<const u32x4*>(bias)[cp], bb);
+#pragma unroll
+    for (int e = 0; e < E; ++e) m[e] = 0.f;                     // ReLU output is >= 0
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const long idx = (((long)b * H + 2 * yo + dy) * W + 2 * xo + dx) * cpack + cp;
+        float f[E];
+        unpack16<T>(xv[idx], f);
+#pragma unroll
+        for (int e = 0; e < E; ++e) { f[e] = fmaxf(f[e] + bb[e], 0.f); }
+        const u32x4 pk = pack16<T>(f);
+        xv[idx] = pk;
+        unpack16<T>(pk, f);                                       // the max of the ROUNDED values, as a separate pool pass would see them
+#pragma unroll
+        for (int e = 0; e < E; ++e) m[e] = fmaxf(m[e], f[e]);
+      }
+    reinterpret_cast<u32x4*>(pooled)[i] = pack16<T>(m);
+  }
+}
+
 }  // namespace
 }  // namespace roma
 
 using namespace roma;
+
+extern "C" int roma_bias_relu_nhwc(void* x, const void* bias, long npix, int C, int dtype, void* stream) {
+  ROMA_REQUIRE(x && bias, ROMA_E_ARG, "roma_bias_relu_nhwc: null pointer");
+  const int e16 = dtype == ROMA_F32 ? 4 : 8;
+  ROMA_REQUIRE(npix > 0 && C > 0 && C % e16 == 0 && aligned16(x) && aligned16(bias), ROMA_E_ALIGN,
+               "roma_bias_relu_nhwc: C = %d must be a multiple of %d and the buffers 16-byte aligned", C, e16);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const long npack = npix * (C / e16);
+  const unsigned grid = (unsigned)((npack + 255) / 256 < 65536 ? (npack + 255) / 256 : 65536);
+  switch (dtype) {
+    case ROMA_F32: hipLaunchKernelGGL((bias_relu_nhwc_kernel<float>), dim3(grid), dim3(256), 0, s, (float*)x, (const float*)bias, npack, C / e16); break;
+    case ROMA_F16: hipLaunchKernelGGL((bias_relu_nhwc_kernel<half_t>), dim3(grid), dim3(256), 0, s, (half_t*)x, (const half_t*)bias, npack, C / e16); break;
+    case ROMA_BF16: hipLaunchKernelGGL((bias_relu_nhwc_kernel<bf16_t>), dim3(grid), dim3(256), 0, s, (bf16_t*)x, (const bf16_t*)bias, npack, C / e16); break;
+    default: ROMA_REQUIRE(false, ROMA_E_DTYPE, "roma_bias_relu_nhwc: dtype %d", dtype);
+  }
+  ROMA_CHECK_LAUNCH();
+}
+
+extern "C" int roma_bias_relu_pool2_nhwc(void* x, const void* bias, void* pooled, int B, int C, int H, int W, int dtype, void* stream) {
+  ROMA_REQUIRE(x && bias && pooled, ROMA_E_ARG, "roma_bias_relu_pool2_nhwc: null pointer");
+  const int e16 = dtype == ROMA_F32 ? 4 : 8;
+  ROMA_REQUIRE(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, ROMA_E_SHAPE, "roma_bias_relu_pool2_nhwc: bad shape B=%d H=%d W=%d (even H, W)", B, H, W);
+  ROMA_REQUIRE(C > 0 && C % e16 == 0 && aligned16(x) && aligned16(bias) && aligned16(pooled), ROMA_E_ALIGN,
+               "roma_bias_relu_pool2_nhwc: C = %d must be a multiple of %d and the buffers 16-byte aligned", C, e16);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const long n = (long)B * (H / 2) * (W / 2) * (C / e16);
+  const unsigned grid = (unsigned)((n + 255) / 256 < 65536 ? (n + 255) / 256 : 65536);
+  switch (dtype) {
+    case ROMA_F32: hipLaunchKernelGGL((bias_relu_pool_nhwc_kernel<float>), dim3(grid), dim3(256), 0, s, (float*)x, (const float*)bias, (float*)pooled, B, H, W, C / e16); break;
+    case ROMA_F16: hipLaunchKernelGGL((bias_relu_pool_nhwc_kernel<half_t>), dim3(grid), dim3(256), 0, s, (half_t*)x, (const half_t*)bias, (half_t*)pooled, B, H, W, C / e16); break;
+    case ROMA_BF16: hipLaunchKernelGGL((bias_relu_pool_nhwc_kernel<bf16_t>), dim3(grid), dim3(256), 0, s, (bf16_t*)x, (const bf16_t*)bias, (bf16_t*)pooled, B, H, W, C / e16); break;
+    default: ROMA_REQUIRE(false, ROMA_E_DTYPE, "roma_bias_relu_pool2_nhwc: dtype %d", dtype);
+  }
+  ROMA_CHECK_LAUNCH();
+}
 
 extern "C" int roma_bias_relu_pool2_nchw(void* x, const void* bias, void* pooled, int B, int C, int H, int W, int dtype, void* stream) {
   ROMA_REQUIRE(x && bias && pooled, ROMA_E_ARG, "roma_bias_relu_pool2_nchw: null pointer");

@@ -36,9 +36,9 @@ class VGG19(nn.Module):
         self.layers = nn.ModuleList(layers[:40])
         self._folded = None
 
-    def fold(self, dtype):
+    def fold(self, dtype, nhwc=False):
         """conv+BN(eval) -> one conv: w' = w*g/sqrt(var+eps), b' = (b-mean)*g/sqrt(var+eps)+beta.  Cached."""
-        key = (dtype, self.layers[0].weight.device, tuple(_ver(p) for p in self.parameters()))
+        key = (dtype, nhwc, self.layers[0].weight.device, tuple(_ver(p) for p in self.parameters()))
         if self._folded is not None and self._folded[0] == key:
             return self._folded[1]
         plan = []
@@ -51,7 +51,7 @@ class VGG19(nn.Module):
                 continue
             bn = self.layers[i + 1]
             s = bn.weight.float() / torch.sqrt(bn.running_var.float() + bn.eps)
-            w = (m.weight.float() * s[:, None, None, None]).to(dtype).contiguous()
+            w = (m.weight.float() * s[:, None, None, None]).to(dtype).contiguous(memory_format=torch.channels_last if nhwc else torch.contiguous_format)
             b = ((m.bias.float() - bn.running_mean.float()) * s + bn.bias.float()).to(dtype)
             plan.append((w, b))
             i += 3
@@ -61,11 +61,14 @@ class VGG19(nn.Module):
     @torch.no_grad()
     def forward(self, x, dtype=torch.float16):
         feats, scale = {}, 1
-        # planar (NCHW) activations: MIOpen's fp16 3x3 solvers measure 18 % faster than its channels-last ones on
-        # gfx950 for this stack (5.7 vs 7.0 ms for the 560 + 864 passes); the decoder's projection GEMM
-        # reads the planar maps as its transposed operand and writes channels-last, so no layout pass is needed
-        x = x.to(dtype).contiguous()
-        plan = self.fold(dtype)
+        # channels-last activations (round 3): with MIOpen's solver search on (enable_miopen_find) the fastest 3x3 solvers on gfx950 are
+        # CK's NHWC implicit-GEMM kernels, and on planar maps MIOpen wraps them in `batched_transpose` passes (1.3 ms per match);
+        # conv + pool chain of the 560 + 864 passes: planar 4.65 ms, channels-last 3.44 ms (tools/scratch/vgg_layout.py).  With the
+        # heuristic solver pick (ROMA_MIOPEN_FIND=0) planar is the faster layout (round 2: 5.7 vs 7.0 ms) and is kept.  The decoder's
+        # projection GEMM reads either layout in place.
+        nhwc = torch.backends.cudnn.benchmark and x.is_cuda
+        x = x.to(dtype).contiguous(memory_format=torch.channels_last if nhwc else torch.contiguous_format)
+        plan = self.fold(dtype, nhwc)
         for i, step in enumerate(plan):
             if step is None:
                 continue                                          # the pool was fused into the layer before it (or is the unused last one)

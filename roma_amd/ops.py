@@ -536,12 +536,20 @@ def normalize_u8(img, mean, std):
     return out
 
 
+def _is_nhwc(x):
+    return x.dim() == 4 and x.shape[1] > 1 and x.stride(1) == 1 and x.is_contiguous(memory_format=torch.channels_last)
+
+
 def bias_relu_(x, bias):
-    """In place max(x + bias[c], 0) on a contiguous planar (B,C,H,W) map — the folded conv+BN+ReLU epilogue of VGG19-BN
+    """In place max(x + bias[c], 0) on a dense (B,C,H,W) map, planar or channels-last — the folded conv+BN+ReLU epilogue of VGG19-BN
     (encoders.py:68-78)."""
     _need_gpu(x, bias)
     B, C, H, W = x.shape
-    assert x.is_contiguous() and bias.dtype == x.dtype and bias.numel() == C and bias.is_contiguous()
+    assert bias.dtype == x.dtype and bias.numel() == C and bias.is_contiguous()
+    if _is_nhwc(x):
+        check(_lib.load().roma_bias_relu_nhwc(_p(x), _p(bias), B * H * W, C, _dt(x), _stream()), "roma_bias_relu_nhwc")
+        return x
+    assert x.is_contiguous()
     step = max(1, 65535 // C)
     for b0 in range(0, B, step):
         xb = x[b0:b0 + step]
@@ -550,11 +558,16 @@ def bias_relu_(x, bias):
 
 
 def bias_relu_pool2_(x, bias):
-    """bias_relu_ fused with the following MaxPool2d(2, 2): x (B,C,H,W) planar is updated in place (the pyramid feature captured
+    """bias_relu_ fused with the following MaxPool2d(2, 2): x (B,C,H,W), planar or channels-last, is updated in place (the pyramid feature captured
     before the pool, encoders.py:68-78) and the pooled (B,C,H/2,W/2) map is returned."""
     _need_gpu(x, bias)
     B, C, H, W = x.shape
-    assert x.is_contiguous() and bias.dtype == x.dtype and bias.numel() == C and bias.is_contiguous() and H % 2 == 0 and W % 2 == 0
+    assert bias.dtype == x.dtype and bias.numel() == C and bias.is_contiguous() and H % 2 == 0 and W % 2 == 0
+    if _is_nhwc(x):
+        out = torch.empty((B, H // 2, W // 2, C), dtype=x.dtype, device=x.device).permute(0, 3, 1, 2)
+        check(_lib.load().roma_bias_relu_pool2_nhwc(_p(x), _p(bias), _p(out), B, C, H, W, _dt(x), _stream()), "roma_bias_relu_pool2_nhwc")
+        return out
+    assert x.is_contiguous()
     out = torch.empty((B, C, H // 2, W // 2), dtype=x.dtype, device=x.device)
     step = max(1, 65535 // C)
     for b0 in range(0, B, step):

@@ -150,7 +150,7 @@ def test_end_to_end_560_coarse_only_fp32(full_model, gp):
 
 
 @pytest.mark.parametrize("gp", GP_MODES)
-def test_end_to_end_full_560_to_864_fp32(full_model, gp):
+def test_end_to_end_full_560_to_864_fp32(full_model, gp, miopen_find):
     """BASELINE.json configs[1] on the real pair: full coarse-to-fine 560 -> 864, fp32 mode, against the reference's
     own output (tests/golden/e2e_864.npz, every 6th pixel + checksums).  Bar: 1e-3 max-abs (north_star)."""
     g = H.golden("e2e_864")
@@ -196,7 +196,7 @@ def _match_560_864(model, dtype, gp="fp32", record=False):
     return out, rec
 
 
-def test_fp16_mode_560_to_864_vs_reference_and_argmax_flips(full_model):
+def test_fp16_mode_560_to_864_vs_reference_and_argmax_flips(full_model, miopen_find):
     """The mode bench.py TIMES (fp16 = the reference's GPU autocast semantics) at the headline configuration, against the
     reference's own (fp32 CPU) output, plus the count of scale-16 arg-max flips against the fp32 mode (the 4096-way arg-max of
     cls_to_flow_refine, utils.py:316, is the path's one discontinuity; SURVEY §7 measured that rounding the features to fp16

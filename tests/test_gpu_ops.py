@@ -805,6 +805,24 @@ def test_bias_relu_pool2_inplace(shape, dtype):
     assert torch.equal(pooled, torch.nn.functional.max_pool2d(ref.float(), 2, 2).to(dtype))
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 64, 56, 40), (1, 512, 70, 70), (2, 128, 6, 10), (1, 256, 35, 35)])
+def test_bias_relu_and_pool_channels_last(shape, dtype):
+    """The channels-last variants (the layout VGG19 runs in with MIOpen's solver search on): same results as the library passes,
+    the map updated in place and still channels-last, the pooled map channels-last too."""
+    x = H.T(R.normal(f"brn.{shape}", shape), DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+    b = H.T(R.normal(f"brn.b.{shape}", (shape[1],)), DEV).to(dtype)
+    ref = torch.relu(x.float() + b.float().view(1, -1, 1, 1)).to(dtype)
+    xs = x.clone(memory_format=torch.preserve_format)
+    assert _ops().bias_relu_(xs, b) is xs and xs.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(xs, ref)
+    if shape[2] % 2 == 0 and shape[3] % 2 == 0:
+        xs = x.clone(memory_format=torch.preserve_format)
+        pooled = _ops().bias_relu_pool2_(xs, b)
+        assert torch.equal(xs, ref) and pooled.is_contiguous(memory_format=torch.channels_last)
+        assert torch.equal(pooled, torch.nn.functional.max_pool2d(ref.float(), 2, 2).to(dtype))
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("C,kpad,M", [(144, 160, 4999), (144, 160, 64), (160, 160, 1000), (48, 160, 333), (24, 32, 777)])
 def test_pointwise_mfma_vs_torch(C, kpad, M, dtype):
