@@ -210,6 +210,17 @@ int roma_refiner_block(const void* x, const void* w25, const float* scale, const
                        const float* bias, void* y, int B, int C, int H, int W, int kpad, int dtype, int x_pitch, int y_pitch,
                        void* stream);
 
+/* The same block at D = 576 (the scale-4 refiner), fp16, as ONE kernel: a 128-pixel x 576-channel output tile per workgroup, the
+ * depthwise result computed once per pixel and fed to the matrix cores through LDS, the 1x1 weights streamed panel by panel.
+ * matcher.py:77-103, 139-140.  x, y: (B,H,W,pitch) channels-last fp16 (must not alias); w25p: the depthwise taps in fp16 (the
+ * reference's autocast convolution weights), panel-major [D/32][25][4][8] (tap t of channel c at [c/32][t][(c%32)/8][c%8]); scale,
+ * shift, bias: (D) fp32; wp: the Conv2d(D, D, 1) weight [out][in] re-tiled by roma_refiner_wide_pack (a HOST function: both
+ * pointers in host memory, D*D 16-bit elements each). */
+int roma_refiner_wide_pack(const void* wt, void* wp, int D);
+int roma_refiner_block_wide(const void* x, const void* w25p, const float* scale, const float* shift, const void* wp,
+                            const float* bias, void* y, int B, int H, int W, int D, int x_pitch, int y_pitch, int dtype,
+                            void* stream);
+
 /* ConvRefiner block back half at mid widths — matcher.py:102 (Conv2d(D, D, 1)) for 32 < D <= 160, fp16 / bf16, on the
  * matrix cores:  y[m][n] = bias[n] + sum_k x[m][k] * wt[n][k];  x, y: (M, pitch) channels-last rows (C used, may alias
  * only if identical); wt: (kpad, kpad) `dtype`, the Conv2d weight itself ([out][in]) zero-padded; bias (kpad) fp32. */

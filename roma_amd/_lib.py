@@ -49,6 +49,9 @@ SIGNATURES = {
     "roma_pointwise_mfma": [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "roma_refiner_block": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                            c_int, c_int, c_void_p],
+    "roma_refiner_wide_pack": [c_void_p, c_void_p, c_int],
+    "roma_refiner_block_wide": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                c_int, c_void_p],
     "roma_refiner_head": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                           c_float, c_float, c_void_p],
     "roma_pointwise_small": [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_int, c_void_p],

@@ -90,6 +90,10 @@ class ConvRefiner(nn.Module):
         fuse_max = int(os.environ.get("ROMA_FUSED_BLOCK", "32"))
         fused = Dp <= min(fuse_max, 160) and dtype in (torch.float16, torch.bfloat16)
         mid = (not fused) and 32 < Dp <= 160 and dtype in (torch.float16, torch.bfloat16) and os.environ.get("ROMA_PW_MFMA", "1") != "0"
+        # D = 576 (the scale-4 refiner), fp16: the whole block as one kernel (ops.refiner_block_wide, csrc/refiner_wide.hip) — prepared
+        # here, used per call when the map fills the chip (see _body): 160 vs 177 us per block at 216^2 x 2, but 97 vs 80 us at 140^2 x 2
+        # (324 tiles of 128 pixels on 256 CUs: one and a quarter rounds)
+        wide = Dp == 576 and dtype == torch.float16 and os.environ.get("ROMA_WIDE_BLOCK", "1") != "0"
         blocks = []
         for blk in [self.block1] + list(self.hidden_blocks):
             dw, bn, _, pw = blk
@@ -105,7 +109,10 @@ class ConvRefiner(nn.Module):
             wt[:D, :D] = pw.weight.float().reshape(D, D).t()            # (in, out): X @ wt
             b = torch.zeros(Dp, device=dev)
             b[:D] = pw.bias.float()
-            if fused:
+            if wide:
+                blocks.append((w25.contiguous(), scale, shift, wt.to(dtype).contiguous(), b.to(dtype),
+                               ops.refiner_wide_taps(w25, dtype), ops.refiner_wide_pack(wt.t().contiguous().to(dtype)), b.contiguous()))
+            elif fused:
                 # one kernel per block (ops.refiner_block): weights zero-padded to kpad channels, 1x1 weight as [out][in]
                 kp = 32 if Dp <= 32 else 160
                 blocks.append((_zero_pad(w25, 25, kp).to(dtype), _zero_pad(scale, kp), _zero_pad(shift, kp),
@@ -120,7 +127,7 @@ class ConvRefiner(nn.Module):
                 blocks.append((w25.contiguous(), scale, shift, wt.to(dtype).contiguous(), b.to(dtype)))
         wo = torch.zeros(Dp, self.out_dim, device=dev)
         wo[:D] = self.out_conv.weight.float().reshape(self.out_dim, D).t()
-        prep = dict(D=D, Dp=Dp, fused=fused, mid=mid, blocks=blocks, wo=wo.contiguous(), bo=self.out_conv.bias.float(),
+        prep = dict(D=D, Dp=Dp, fused=fused, mid=mid, wide=wide, blocks=blocks, wo=wo.contiguous(), bo=self.out_conv.bias.float(),
                     we=self.disp_emb.weight.float().reshape(-1, 2).contiguous(), be=self.disp_emb.bias.float())
         self._prep = (key, prep)
         return prep
@@ -158,13 +165,20 @@ class ConvRefiner(nn.Module):
             ops.local_correlation(d[:, :C], yy, r, flow=flow, out=d[:, 2 * C + E:D], batch_shift=batch_shift)   # :121-125
         M = B * h * w
         cur = buf
+        if P["wide"] and B * ((h + 7) // 8) * ((w + 15) // 16) >= 2 * 256:
+            nxt = torch.empty_like(buf)
+            for blk in P["blocks"]:                                                            # :139-140
+                ops.refiner_block_wide(cur, blk[5], blk[1], blk[2], blk[6], blk[7], out=nxt)
+                cur, nxt = nxt, cur
+            return cur, P
         if P["fused"]:
             nxt = torch.empty_like(buf)
             for (w25, scale, shift, wt, b) in P["blocks"]:                                     # :139-140
                 ops.refiner_block(cur, w25, scale, shift, wt, b, Dp, out=nxt)
                 cur, nxt = nxt, cur
             return cur, P
-        for (w25, scale, shift, wt, b) in P["blocks"]:                                         # :139-140
+        for blk in P["blocks"]:                                                                # :139-140
+            w25, scale, shift, wt, b = blk[:5]
             t = ops.dwconv5x5_bn_relu(cur.permute(0, 3, 1, 2), w25, scale, shift)
             rows = t.permute(0, 2, 3, 1).reshape(M, Dp)
             if P["mid"]:

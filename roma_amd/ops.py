@@ -592,6 +592,37 @@ def pointwise_mfma(rows, wt, bias, C, out=None):
     return out
 
 
+def refiner_wide_pack(wt_out_in):
+    """Re-tile a (D, D) [out][in] 16-bit 1x1-conv weight into the panel-major layout roma_refiner_block_wide streams (host-side
+    helper of the library; returns a tensor on wt's device)."""
+    w = wt_out_in.detach().to("cpu").contiguous()
+    assert w.dim() == 2 and w.shape[0] == w.shape[1] and w.element_size() == 2
+    out = torch.empty_like(w)
+    check(_lib.load().roma_refiner_wide_pack(w.data_ptr(), out.data_ptr(), w.shape[0]), "roma_refiner_wide_pack")
+    return out.to(wt_out_in.device)
+
+
+def refiner_wide_taps(w25, dtype=torch.float16):
+    """(25, D) tap-major depthwise weights -> the panel-major 16-bit layout roma_refiner_block_wide stages: [D/32][25][4][8]."""
+    D = w25.shape[1]
+    return w25.reshape(25, D // 32, 4, 8).permute(1, 0, 2, 3).contiguous().to(dtype)
+
+
+def refiner_block_wide(x_nhwc, w25p, scale, shift, wp, bias, out=None):
+    """One fused ConvRefiner block (matcher.py:77-103) at D = 576, fp16: x_nhwc (B,h,w,576) contiguous, w25p from refiner_wide_taps,
+    scale / shift / bias (576) fp32, wp from refiner_wide_pack.  out must not alias x."""
+    _need_gpu(x_nhwc, w25p, scale, shift, wp, bias, out)
+    B, H, W, D = x_nhwc.shape
+    assert x_nhwc.is_contiguous() and w25p.shape == (D // 32, 25, 4, 8) and w25p.dtype == x_nhwc.dtype and w25p.is_contiguous()
+    assert all(t.dtype == torch.float32 and t.numel() == D and t.is_contiguous() for t in (scale, shift, bias))
+    if out is None:
+        out = torch.empty_like(x_nhwc)
+    assert out.shape == x_nhwc.shape and out.is_contiguous() and out.data_ptr() != x_nhwc.data_ptr()
+    check(_lib.load().roma_refiner_block_wide(_p(x_nhwc), _p(w25p), _p(scale), _p(shift), _p(wp), _p(bias), _p(out), B, H, W, D, D, D,
+                                              _dt(x_nhwc), _stream()), "roma_refiner_block_wide")
+    return out
+
+
 def refiner_block(x_nhwc, w25, scale, shift, wt, bias, C, out=None):
     """One fused ConvRefiner block (depthwise 5x5 + BN + ReLU + 1x1 conv, matcher.py:77-103) for C <= 160, fp16/bf16.
     x_nhwc: (B,h,w,pitch) contiguous; w25 (25,kpad), wt (kpad,kpad) [out][in] in x's dtype; scale/shift/bias (kpad) fp32."""

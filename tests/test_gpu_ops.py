@@ -823,6 +823,34 @@ def test_bias_relu_and_pool_channels_last(shape, dtype):
         assert torch.equal(pooled, torch.nn.functional.max_pool2d(ref.float(), 2, 2).to(dtype))
 
 
+@pytest.mark.parametrize("shape", [(2, 37, 45), (1, 8, 16), (1, 140, 140), (3, 5, 3)])
+def test_refiner_block_wide_vs_the_two_kernel_path(shape):
+    """The fused D = 576 block (depthwise 5x5 + BN + ReLU + 1x1 in one kernel, matcher.py:77-103) against the path it replaces —
+    ops.dwconv5x5_bn_relu (checked against torch elsewhere in this file) followed by an fp32 matmul on the fp16-rounded
+    intermediate — on maps with partial tiles on both borders, and against torch's own depthwise conv."""
+    ops = _ops()
+    B, h, w = shape
+    D = 576
+    g = torch.Generator().manual_seed(h * 1000 + w)
+    x = torch.randn(B, h, w, D, generator=g).half().to(DEV)
+    w25 = (torch.randn(25, D, generator=g) * 0.2).to(DEV)
+    scale = (torch.rand(D, generator=g) + 0.5).to(DEV)
+    shift = (torch.randn(D, generator=g) * 0.1).to(DEV)
+    wt = (torch.randn(D, D, generator=g) / D ** 0.5).half().to(DEV)          # [out][in]
+    bias = (torch.randn(D, generator=g) * 0.1).to(DEV)
+    w25 = w25.half().float()                                                  # the fused kernel holds its taps in fp16 (autocast semantics)
+    out = ops.refiner_block_wide(x, ops.refiner_wide_taps(w25), scale, shift, ops.refiner_wide_pack(wt), bias)
+    t = ops.dwconv5x5_bn_relu(x.permute(0, 3, 1, 2), w25, scale, shift).permute(0, 2, 3, 1)
+    ref = (t.float().reshape(-1, D) @ wt.float().t() + bias).reshape(B, h, w, D)
+    tol = 2 ** -9 * max(1.0, float(ref.abs().max()))
+    assert maxerr(out, ref) <= tol
+    # and the depthwise half against torch (fp32 conv on the same rounded input)
+    tt = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w25.t().reshape(D, 1, 5, 5), padding=2, groups=D)
+    tt = torch.relu(tt * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)).half().float().permute(0, 2, 3, 1)
+    ref2 = (tt.reshape(-1, D) @ wt.float().t() + bias).reshape(B, h, w, D)
+    assert maxerr(out, ref2) <= 2 * tol
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("C,kpad,M", [(144, 160, 4999), (144, 160, 64), (160, 160, 1000), (48, 160, 333), (24, 32, 777)])
 def test_pointwise_mfma_vs_torch(C, kpad, M, dtype):

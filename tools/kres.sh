@@ -1,6 +1,6 @@
 #!/bin/bash
 # Register / occupancy table of every kernel in one .hip file (compiler view): tools/kres.sh roma_amd/csrc/local_corr_rows.hip
-/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form -c "$1" -o /dev/null -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c '
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 $KRES_FLAGS -c "$1" -o /dev/null -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c '
 import sys,re
 rows=[];cur=None
 for l in sys.stdin:
