@@ -177,8 +177,8 @@ def parity_legs(device, dtype, pin, images):
 LC_SHAPES = [("L16", 512, 40, 7), ("L8", 512, 70, 3), ("L4", 256, 140, 2), ("U8", 512, 108, 3), ("U4", 256, 216, 2)]
 # what roma_local_corr's AUTO policy launches for 16-bit channels-last inputs (roma_amd/csrc/local_corr.hip, launch_any): names as
 # rocprofv3 shows them
-LC_KERNELS = ("local_corr_rows_kernel (row-streaming, r <= 3 and C = 256 / 512: the scale-8 and scale-4 levels), local_corr_mfma_kernel "
-              "(8x4-pixel tiles, 32-channel chunks: the r = 7 scale-16 level)")
+LC_KERNELS = ("local_corr_rows_kernel (row-streaming; all five levels of the 560 -> 864 match: r <= 3 with C = 256 / 512, and the r = 7 "
+              "scale-16 level, whose 40 x 40 map fits the wide-box instantiation)")
 
 
 def known_warp_flow(scale_unused, b, h, w, device, upsample_unused, rot_deg=8.0, scale=1.08, shift=0.04, jitter_px=0.5, gen=None):

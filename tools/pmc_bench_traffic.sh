@@ -8,8 +8,8 @@ O=$R/gpurun_out/traffic
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 BENCH="$R/bench.py --no-cpu --no-microbench --steps 3 --warmup 1"
-timeout -k 5 150 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/bench_fetch -- python3 $BENCH > $O/fetch.log 2>&1
-timeout -k 5 150 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/bench_write -- python3 $BENCH > $O/write.log 2>&1
+timeout -k 5 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/bench_fetch -- python3 $BENCH > $O/fetch.log 2>&1
+timeout -k 5 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/bench_write -- python3 $BENCH > $O/write.log 2>&1
 python3 $R/tools/pmc_traffic.py $O/bench_fetch $O/bench_write 44550979.2 > $R/gpurun_out/local_corr_traffic.json
 cp $R/gpurun_out/local_corr_traffic.json $R/profiles/local_corr_traffic.json
 cd $R
