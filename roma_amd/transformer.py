@@ -19,13 +19,19 @@ import torch.nn.functional as F
 
 from . import ops
 
-# ROMA_ATTENTION=hip: ops.attention (the hand-written flash-style kernel, roma_attention_fwd) for the 64-wide heads of DINOv2 in the
-# 16-bit modes instead of torch's scaled_dot_product_attention.  Opt-in for now: it is as accurate as SDPA against an fp64 attention
-# (identical max / rms error on every shape tried) and as fast at one pair per step (59.6 vs 62.5 us per layer; 345 vs 320 us at 8 pairs),
-# but the end-to-end fp16 statistics moved with it (32 instead of 17 of 3 200 coarse arg-max flips against the fp32 mode at 560 -> 864;
-# torch's `math` SDPA backend, a third realisation of the same 16-bit noise, gives 34 — the GP amplifies any change of that noise), and
-# the fp16 statistics pinned in the tests / DESIGN.md §4 belong to the SDPA realisation.
-ATTENTION_KERNEL = os.environ.get("ROMA_ATTENTION", "sdpa") == "hip"
+# Attention of the 64-wide DINOv2 heads in the 16-bit modes: torch's scaled_dot_product_attention (aotriton; the default) or
+# ops.attention (the hand-written flash-style kernel, roma_attention_fwd; ROMA_ATTENTION=hip).  Both are equally accurate against an
+# fp64 attention (identical max / rms error on every shape tried), and stand-alone the hand-written kernel is faster at one
+# pair per step (53.2 vs 59.1 us per layer at B = 2, slower at eight pairs: 355 vs 319 us at B = 16).  Round 3 tried it as the default
+# up to B = 4 and measured NO step-time gain (18.38 vs 18.28 ms: the 24 layers sit beside the VGG stream, which fills what they free),
+# while the fp16 statistics moved inside their pinned bounds but visibly (32 instead of 17 of 3 200 coarse arg-max flips against the
+# fp32 mode at 560 -> 864, warp p99 against the reference 0.12 instead of 0.04: the GP amplifies any change of the 16-bit noise into
+# different near-tie decisions; torch's `math` SDPA backend gives 34 flips) — so it stays opt-in.
+ATTENTION_KERNEL = os.environ.get("ROMA_ATTENTION", "sdpa")       # "sdpa" | "hip" (tests may also set True / False)
+
+
+def _use_hip_attention(batch):
+    return ATTENTION_KERNEL in (True, "hip")
 
 
 class Attention(nn.Module):
@@ -41,7 +47,7 @@ class Attention(nn.Module):
         B, N, C = x.shape
         hd = C // self.num_heads
         qkv = self.qkv(x).view(B, N, 3, self.num_heads, hd)
-        if hd == 64 and qkv.dtype in (torch.float16, torch.bfloat16) and ATTENTION_KERNEL:
+        if hd == 64 and qkv.dtype in (torch.float16, torch.bfloat16) and _use_hip_attention(B):
             # the hand-written flash-style kernel reads q / k / v in place and writes the projection's input layout
             return self.proj(ops.attention(qkv, n_valid))
         qkv = qkv.permute(2, 0, 3, 1, 4)

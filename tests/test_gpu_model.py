@@ -292,7 +292,7 @@ def test_fp16_mode_with_the_hand_written_attention_kernel(full_model):
         f_hip = full_model.encoder.vit_features(x).float()
         w_hip, c_hip = full_model.match(H.asset("sacre_coeur_A.jpg"), H.asset("sacre_coeur_B.jpg"), device=DEV)
     finally:
-        TR.ATTENTION_KERNEL = False
+        TR.ATTENTION_KERNEL = "sdpa"
         _set_dtype(full_model, torch.float32)
     rel = float((f_hip - f_sdpa).pow(2).mean().sqrt() / f_sdpa.pow(2).mean().sqrt())
     dw = (w_hip - w_sdpa).abs()
