@@ -382,6 +382,19 @@ def gen_e2e(ref, full=False):
     save("e2e_112", **{k: v for k, v in out.items() if k.startswith("r112")})
 
 
+def gen_e2e_second_pair(ref):
+    """A second photograph pair for the headline configuration (BASELINE.json configs[1], 560 -> 864, fp32, seeded weights): the
+    reference's other bundled asset pair, toronto_A/B.jpg (a wide-baseline, low-overlap pair — a different regime from sacre_coeur).
+    About a minute and a half on 8 cores; run with --only e2e2."""
+    model = build_full_reference(560, 864)
+    pa, pb = (os.path.join(HERE, "assets", f"toronto_{n}.jpg") for n in "AB")
+    t = time.time()
+    warp, cert = model.match(pa, pb, device="cpu")
+    print(f"  toronto 560->864 full match: {time.time()-t:.1f}s")
+    save("e2e_864_toronto", warp_stats=R.checksum(warp.numpy()), cert_stats=R.checksum(cert.numpy()),
+         warp_sample=warp.numpy()[::6, ::6].copy(), cert_sample=cert.numpy()[::6, ::6].copy())
+
+
 # ------------------------------------------------------------------------------------------------
 # 10. TinyRoMa: corr_volume, pos_embed (fast path B=1, exact path B>1), forward/match on a stand-in backbone
 # ------------------------------------------------------------------------------------------------
@@ -412,7 +425,7 @@ def gen_tiny(ref):
 
 
 GENS = {"local_corr": gen_local_corr, "cls": gen_cls, "gp": gen_gp, "refiner": gen_refiner, "decoder": gen_decoder,
-        "post": gen_post, "kde": gen_kde, "preproc": gen_preproc, "e2e": gen_e2e, "tiny": gen_tiny}
+        "post": gen_post, "kde": gen_kde, "preproc": gen_preproc, "e2e": gen_e2e, "tiny": gen_tiny, "e2e2": gen_e2e_second_pair}
 
 
 def main():
@@ -423,8 +436,8 @@ def main():
     torch.set_grad_enabled(False)
     ref = import_reference()
     for name, fn in GENS.items():
-        if args.only and name not in args.only:
-            continue
+        if (args.only and name not in args.only) or (name == "e2e2" and not (args.only and "e2e2" in args.only)):
+            continue                                               # e2e2 (the second photograph pair, ~1.5 min) only on request
         print(f"[{name}]")
         t = time.time()
         if name == "e2e":

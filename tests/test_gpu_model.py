@@ -171,6 +171,29 @@ def test_end_to_end_full_560_to_864_fp32(full_model, gp, miopen_find):
     assert float(dw.median()) < 1e-6 and float(dc.median()) < 1e-4
 
 
+@pytest.mark.parametrize("gp", GP_MODES)
+def test_end_to_end_full_560_to_864_fp32_second_pair(full_model, gp, miopen_find):
+    """The same configuration on the reference's OTHER bundled photograph pair (toronto_A/B.jpg: wide baseline, little overlap — a
+    different regime from sacre_coeur, and a different draw of the GP's ill-conditioned directions), against the reference's own
+    output (tests/golden/e2e_864_toronto.npz, make_golden.py --only e2e2).  Same 1e-3 max-abs bar."""
+    g = H.golden("e2e_864_toronto")
+    _set_dtype(full_model, torch.float32, gp)
+    full_model.h_resized = full_model.w_resized = 560
+    full_model.upsample_res = (864, 864)
+    try:
+        warp, cert = full_model.match(H.asset("toronto_A.jpg"), H.asset("toronto_B.jpg"), device=DEV)
+    finally:
+        full_model.h_resized = full_model.w_resized = 112
+        full_model.upsample_res = (168, 168)
+    dw = (warp.cpu()[::6, ::6] - H.T(g["warp_sample"])).abs()
+    dc = (cert.cpu()[::6, ::6] - H.T(g["cert_sample"])).abs()
+    print(f"toronto 560->864 fp32 gp={gp}: warp max {float(dw.max()):.2e} frac>1e-3 {float((dw > 1e-3).float().mean()):.2e}; "
+          f"cert max {float(dc.max()):.2e} frac>1e-3 {float((dc > 1e-3).float().mean()):.2e}")
+    assert float(dw.max()) < E2E_BOUNDS[("f864", gp)][0] and float(dc.max()) < E2E_BOUNDS[("f864", gp)][1]
+    assert float(dw.median()) < 1e-6 and float(dc.median()) < 1e-4
+    np.testing.assert_allclose(R.checksum(warp.cpu().numpy())[:3], g["warp_stats"][:3], rtol=1e-4, atol=1e-2)
+
+
 # (warp max-abs, certainty max-abs) bounds; measured values in the comments (MI355X, round 2)
 E2E_BOUNDS = {
     ("c560", "fp64"): (5e-6, 1e-3),      # measured 2.4e-7 / 5.2e-4
