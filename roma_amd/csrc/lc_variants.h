@@ -16,7 +16,9 @@ struct LCTileParams {
   int tiles_x, tiles_y;
   int f1_shift;
   float scale;
-  float inv_tiles_per_img, inv_tiles_x;   // 1 / (tiles_x tiles_y), 1 / tiles_x (row-streaming kernel: block id -> tile without integer division)
+  float inv_tiles_per_img, inv_tiles_x;   // 1 / (tiles_x tiles_y bands), 1 / tiles_x (row-streaming kernel: block id -> tile without integer division)
+  int bands;                              // row-streaming kernel: workgroups per tile (each streams a band of the tile's box rows); set by its launcher
+  float inv_bands;
 };
 
 // one 8x8 tile per workgroup (local_corr_t8.hip): 16-bit channels-last inputs, r in 1..3, C a multiple of 32

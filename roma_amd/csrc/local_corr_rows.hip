@@ -23,6 +23,8 @@
 // ring (patch path below).  r = 7 on small maps (the 40 x 40 scale-16 level): up to three column blocks per group and a box that may be
 // the whole map, so every tile streams.  Tile = 8 x 8 pixels, 4 waves (an 8 x 16 / 8-wave variant measured 1.5-2x slower: its waves
 // idle through half of the 26 stages and 150 VGPRs leave one workgroup per CU at C = 512; gpurun_out/r3_lcb3.txt).
+#include <algorithm>
+#include <cstdlib>
 #include "common.h"
 #include "lc_device.h"
 #include "lc_variants.h"
@@ -107,7 +109,9 @@ __global__ __launch_bounds__(64 * NW) void local_corr_rows_kernel(LCTileParams p
   const int tiles_per_img = p.tiles_x * p.tiles_y;
   const int wid = xcd_remap(blockIdx.x, gridDim.x);
   const int b = (int)(((float)wid + 0.5f) * p.inv_tiles_per_img);
-  const int t = wid - b * tiles_per_img;
+  const int tb = wid - b * tiles_per_img * p.bands;
+  const int t = (int)(((float)tb + 0.5f) * p.inv_bands);
+  const int band = __builtin_amdgcn_readfirstlane(tb - t * p.bands);   // this workgroup's share of the tile (see "bands" below)
   const int tyi = (int)(((float)t + 0.5f) * p.inv_tiles_x);
   const int ty0 = tyi * TH, tx0 = (t - tyi * p.tiles_x) * kTW;
   int b1 = b + p.f1_shift;
@@ -191,6 +195,15 @@ __global__ __launch_bounds__(64 * NW) void local_corr_rows_kernel(LCTileParams p
   const int bw = __builtin_amdgcn_readfirstlane(tempty ? 0 : bx1 - bx0 + 1);
   const int nrows = __builtin_amdgcn_readfirstlane(tempty ? 0 : max(ba1 - ba0 + 1, 0));
   ok = ok && bw <= BWMAX && nrows <= G::MAXROWS;
+  // Bands: a launch with fewer tiles than the chip has room for (B = 2 at the 40 x 40 level: 50 tiles for 256 CUs, each streaming up to
+  // the whole map) gets `bands` workgroups per tile from the launcher.  The emit positions j = 0 .. nrows (box row j blended with row
+  // j - 1; j = nrows is the virtual row) are cut into runs of `per`; band k stages rows [k per - 1, (k + 1) per) and owns the output
+  // rows whose emit position, clamped to [0, nrows], falls into its run: a partition, so every output element is written exactly once
+  // and no workgroup waits for another (the first staged row of a band only fills the previous-row registers: what it emits lands in
+  // a row of this workgroup's LDS image that another band owns and is never stored).  Patch path: the bands share out the pixels.
+  const int per = (int)(((float)(nrows + p.bands) + 0.5f) * p.inv_bands);      // ceil((nrows + 1) / bands)
+  const int c_lo = band * per;
+  const int js = max(c_lo - 1, 0), je = min(c_lo + per, nrows);                // staged box rows [js, je)
 
   if constexpr (G::kPatchPath) {
     if (!__builtin_amdgcn_readfirstlane((int)ok)) {
@@ -216,7 +229,12 @@ __global__ __launch_bounds__(64 * NW) void local_corr_rows_kernel(LCTileParams p
       const float qax = s_ax[g * 16 + mrec], qay = s_ay[g * 16 + mrec];
       const bool hit = gpy + (mrec >> 2) < H && gpx + (mrec & 3) < W && max(qx0 - R, 0) <= min(qx0 + R + 1, W - 1) &&
                        max(qy0 - R, 0) <= min(qy0 + R + 1, H - 1);
-      const uint32_t act = (uint32_t)(__ballot(hit) & 0xffffull);
+      uint32_t own = 0xffffu;                                     // this band's pixels of the group: m = band (mod bands)
+      if (p.bands > 1) {
+        own = 0;
+        for (int mm = band; mm < 16; mm += p.bands) own |= 1u << mm;
+      }
+      const uint32_t act = (uint32_t)(__ballot(hit) & 0xffffull) & own;
       T* ob = p.out_nhwc ? out + (((size_t)b * H + gpy) * W + gpx) * p.out_pitch : out + ((size_t)b * p.out_pitch * H + gpy) * W + gpx;
       const uint32_t plane = (uint32_t)(H * W);
       auto out_off = [&](int mm, int kk) -> uint32_t {
@@ -224,7 +242,7 @@ __global__ __launch_bounds__(64 * NW) void local_corr_rows_kernel(LCTileParams p
         return p.out_nhwc ? (uint32_t)((dy * W + dx) * p.out_pitch + kk) : (uint32_t)kk * plane + (uint32_t)(dy * W + dx);
       };
       for (int mm = 0; mm < 16; ++mm) {                           // zeros for pixels inside the image that gather nothing
-        if (((act >> mm) & 1u) || gpy + (mm >> 2) >= H || gpx + (mm & 3) >= W) continue;
+        if (((act >> mm) & 1u) || !((own >> mm) & 1u) || gpy + (mm >> 2) >= H || gpx + (mm & 3) >= W) continue;
         if (lane < K) ob[out_off(mm, lane)] = from_f32<T>(0.f);
       }
       const int nstw = __builtin_popcount(act) * N2 * NCB;
@@ -332,7 +350,7 @@ __global__ __launch_bounds__(64 * NW) void local_corr_rows_kernel(LCTileParams p
   (void)ok;                                                      // r >= 4: the host admits only maps every box of which fits (W <= BWMAX - 1)
 
   // =========================== streaming path ===========================
-  const int nst = nrows * NCB;
+  const int nst = max(je - js, 0) * NCB;
   // DMA plan: wave-instruction ii = k NW + wave of a stage covers LDS bytes [1024 ii, 1024 ii + 1024) = pixels 2 ii, 2 ii + 1
   uint32_t voff[NIW];
   const int ni = (bw + 1) >> 1;
@@ -434,7 +452,7 @@ __global__ __launch_bounds__(64 * NW) void local_corr_rows_kernel(LCTileParams p
 
   auto run = [&](auto nwi_c) {
     constexpr int NWI = decltype(nwi_c)::value;
-    const T* rb = f1 + (size_t)ba0 * W * p.f1_pitch;             // next stage to issue: row pointer (channel block 0)
+    const T* rb = f1 + (size_t)(ba0 + js) * W * p.f1_pitch;      // next stage to issue: row pointer (channel block 0)
     const size_t rstride = (size_t)W * p.f1_pitch;
     const uint32_t dst0 = lds0 + (uint32_t)(wave * 1024);
     auto issue = [&](auto slot_c, auto cb_c) {
@@ -468,7 +486,7 @@ __global__ __launch_bounds__(64 * NW) void local_corr_rows_kernel(LCTileParams p
           }
           raw_barrier();
           const int cb = u % NCB;
-          const int jr = NCB == 1 ? st : st >> 1;
+          const int jr = js + (NCB == 1 ? st : st >> 1);
           if (jr >= gs0 && jr <= gs1) {
             // B fragments of two blocks at a time: sixteen reads in flight before the first MFMA waits
 #pragma unroll
@@ -512,7 +530,7 @@ __global__ __launch_bounds__(64 * NW) void local_corr_rows_kernel(LCTileParams p
     if (n_w * 2 <= NIW) run(std::integral_constant<int, (NIW + 1) / 2>{});
     else run(std::integral_constant<int, NIW>{});
   }
-  if (gvirt) {                                                   // the virtual row below the image
+  if (gvirt && c_lo <= nrows && nrows < c_lo + per) {            // the virtual row below the image (the band that owns position nrows)
     float4_t z[NBLK];
 #pragma unroll
     for (int k = 0; k < NBLK; ++k) z[k] = float4_t{0.f, 0.f, 0.f, 0.f};
@@ -521,6 +539,29 @@ __global__ __launch_bounds__(64 * NW) void local_corr_rows_kernel(LCTileParams p
 
   // ---- write the group's output image: wave-private, no barrier; 32-bit element offsets from a wave-uniform base ----
   const T* ot = reinterpret_cast<const T*>(ot_all + g * G::OTB);
+  if (p.bands > 1) {
+    // this band's rows of every pixel: image rows i in [1, N1] whose emit position clamp(i + wy, 0, nrows) lies in [c_lo, c_lo + per)
+    if (c_lo > nrows) return;
+    const uint32_t plane = (uint32_t)(H * W);
+    T* ob = p.out_nhwc ? out + (((size_t)b * H + gpy) * W + gpx) * p.out_pitch : out + ((size_t)b * p.out_pitch * H + gpy) * W + gpx;
+    for (int m = 0; m < 16; ++m) {
+      const int dy = m >> 2, dx = m & 3;
+      if (gpy + dy >= H || gpx + dx >= W) continue;
+      const int wy = __builtin_amdgcn_readfirstlane(s_y0[g * 16 + m]) - R - ba0;
+      const int i_lo = c_lo <= 0 ? 1 : max(1, c_lo - wy);
+      const int i_hi = c_lo + per > nrows ? N1 : min(N1, c_lo + per - 1 - wy);
+      const int kk0 = (i_lo - 1) * N1, cnt = (i_hi - i_lo + 1) * N1;
+      const T* om = ot + m * (PPB / 2) + N1 + kk0;
+      if (p.out_nhwc) {
+        T* o = ob + (uint32_t)((dy * W + dx) * p.out_pitch + kk0);
+        for (int e = lane; e < cnt; e += 64) o[e] = om[e];
+      } else {
+        T* o = ob + (uint32_t)kk0 * plane + (uint32_t)(dy * W + dx);
+        for (int e = lane; e < cnt; e += 64) o[(uint32_t)e * plane] = om[e];
+      }
+    }
+    return;
+  }
   if (p.out_nhwc) {
     T* ob = out + (((size_t)b * H + gpy) * W + gpx) * p.out_pitch;
     for (int e = lane; e < 16 * K; e += 64) {
@@ -547,9 +588,15 @@ int launch_rows(LCTileParams p, hipStream_t stream) {
   if (int rc = ensure_dyn_smem(reinterpret_cast<const void*>(local_corr_rows_kernel<T, R, NCB, NW>), (int)smem, attr_done, "roma_local_corr")) return rc;
   p.tiles_x = (p.W + kTW - 1) / kTW;
   p.tiles_y = (p.H + 2 * NW - 1) / (2 * NW);
-  p.inv_tiles_per_img = 1.0f / (float)(p.tiles_x * p.tiles_y);
+  // bands (see the kernel): launches that leave most of the chip idle split every tile's box rows over several workgroups
+  const int tiles = p.B * p.tiles_x * p.tiles_y;
+  const int room = R >= 4 ? 256 : 512, most = R >= 4 ? 8 : 4;
+  p.bands = tiles > 0 && tiles < room ? std::min(std::max(room / tiles, 1), most) : 1;
+  if (const char* e = getenv("ROMA_LC_BANDS")) { const int v = atoi(e); if (v >= 1 && v <= 16) p.bands = v; }
+  p.inv_bands = 1.0f / (float)p.bands;
+  p.inv_tiles_per_img = 1.0f / (float)(p.tiles_x * p.tiles_y * p.bands);
   p.inv_tiles_x = 1.0f / (float)p.tiles_x;
-  const int grid = p.B * p.tiles_x * p.tiles_y;
+  const int grid = tiles * p.bands;
   ROMA_REQUIRE(grid < (1 << 21), ROMA_E_SHAPE, "roma_local_corr: %d tiles in one launch (row-streaming kernel: < 2^21)", grid);
   hipLaunchKernelGGL((local_corr_rows_kernel<T, R, NCB, NW>), dim3(grid), dim3(64 * NW), smem, stream, p);
   ROMA_CHECK_LAUNCH();

@@ -515,6 +515,46 @@ def test_local_corr_rows_kernel_on_concat_slices_with_batch_shift_and_identity_f
         assert float(buf[..., 8 + C + K:].abs().max()) == 0.0 and float(buf[..., :8].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("kind", ["coherent", "adversarial", "mixed"])
+@pytest.mark.parametrize("shape", [(2, 512, 40, 40, 7), (2, 512, 70, 70, 3), (1, 256, 37, 53, 2), (2, 256, 19, 45, 3), (1, 512, 21, 9, 1)])
+def test_local_corr_rows_kernel_bands_partition_the_output(shape, kind, monkeypatch):
+    """The row-streaming kernel gives a tile several workgroups when a launch is small (local_corr_rows.hip, "bands": each streams a
+    band of the tile's box rows / takes a share of the patch pixels and stores only the output rows it owns).  Whatever the band
+    count — forced here through ROMA_LC_BANDS, which the launcher reads per call — every output element must be written exactly
+    once with the same arithmetic: results are BIT-identical to the one-workgroup-per-tile launch, in both output layouts, into a
+    buffer pre-filled with NaN (an element nobody owns would stay NaN), borders / NaN / far-out-of-range flow included."""
+    B, C, h, w, r = shape
+    ops = _ops()
+    f0 = H.T(R.normal(f"lcb.{shape}.f0", (B, C, h, w))).half().to(DEV).contiguous(memory_format=torch.channels_last)
+    f1 = H.T(R.normal(f"lcb.{shape}.f1", (B, C, h, w))).half().to(DEV).contiguous(memory_format=torch.channels_last)
+    flow = R.coherent_flow(f"lcb.{shape}.flow", B, h, w)
+    if kind == "adversarial":
+        flow = R.adversarial_flow(f"lcb.{shape}.flow", B, h, w)
+    elif kind == "mixed":
+        adv = R.adversarial_flow(f"lcb.{shape}.adv", B, h, w)
+        flow[:, :, h // 3: 2 * h // 3, w // 4: w // 2] = adv[:, :, h // 3: 2 * h // 3, w // 4: w // 2]
+        flow[:, 0, 0, 0] = float("nan")
+        flow[:, 1, -1, -1] = 1e30
+        flow[:, :, 1, 2] = -7.0
+        flow[:, 1, : h // 4] -= 1.5                                                            # windows hanging over the top edge
+        flow[:, 1, -(h // 4):] += 1.5                                                          # ... and the bottom edge (virtual row)
+    flow = H.T(flow, DEV)
+    K = (2 * r + 1) ** 2
+
+    def run(bands, nhwc):
+        monkeypatch.setenv("ROMA_LC_BANDS", str(bands))
+        out = torch.full((B, K, h, w), float("nan"), dtype=torch.float16, device=DEV)
+        if nhwc:
+            out = out.contiguous(memory_format=torch.channels_last)
+        return ops.local_correlation(f0, f1, r, flow=flow, variant="rows8", out=out)
+
+    for nhwc in (True, False):
+        one = run(1, nhwc)
+        assert torch.isfinite(one.float()).all()
+        for bands in (2, 3, 5, 8):
+            assert torch.equal(run(bands, nhwc), one), (bands, nhwc)
+
+
 def test_cos_kernel_reads_channels_last_slices_in_place():
     ops = _ops()
     buf = torch.randn(2, 10, 12, 200, device=DEV).half()                                       # a wider channels-last buffer
