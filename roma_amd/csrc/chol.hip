@@ -11,12 +11,17 @@
 // 3 261 s_nop hazard pads, 1 796 v_writelane SGPR spills): 65 us per block.  This version keeps the block in LDS and works in
 // 16-column panels with the whole 256-thread workgroup:
 //   per panel p:  (1) wave 0 factors the 16 x 16 diagonal block in registers (lane = row, 120 broadcasts, no predication: the
-//                     strict upper triangle is allowed to hold garbage, nothing reads it);
+//                     strict upper triangle is allowed to hold garbage, nothing reads it; one v_rcp per pivot on the dependent
+//                     chain, the 1 / sqrt of the stored column off it);
 //                 (2) one thread per row below solves its 16 entries of the panel against that block (L11 is a broadcast read);
-//                 (3) all threads apply the rank-16 update to the trailing lower triangle;
+//                 (3) the rank-16 update of the trailing lower triangle, one 4 x 4 register tile per thread;
 //   inverse:      (4) the four 16 x 16 diagonal blocks of L^-1 by forward substitution (one thread per column), then the
 //                     off-diagonal blocks as small products, W21 = -W22 (L21 W11), first inside each 32 x 32 half, then the
 //                     32 x 32 block below the diagonal.
+// Round 3 (tools/scratch/chol_prof: wall-clock stamps inside the diagonal workgroup of a blocked step): of 44 us per step, 10 us were
+// 32 SERIALISED global loads (hipcc had put a vmcnt(0) into every iteration of the tile-load loops), 13 us the four diagonal blocks
+// (IEEE sqrt + IEEE division per pivot), 6 us the trailing updates; with the loads batched, rcp / rsq pivots and register-tiled updates a
+// step's workgroup takes 31 us, the 25-step chain 0.96 ms instead of 1.25 ms, ops.spd_solve 1.17 ms instead of 1.49 ms.
 #include <type_traits>
 #include "common.h"
 
@@ -47,13 +52,19 @@ __device__ __forceinline__ void chol_factor_lds(float* __restrict__ Ls, float* _
       int bad = 0;
 #pragma unroll
       for (int k = 0; k < PB; ++k) {
-        const float akk = lane_bcast(d[k], k);
+        float akk = lane_bcast(d[k], k);
         if (!(akk > 0.f) && bad == 0) bad = o + k + 1;           // non-positive or NaN pivot: clamped, recorded
-        const float inv = 1.f / sqrtf(fmaxf(akk, 1e-30f));
-        d[k] *= inv;                                             // rows i >= k: L[i][k] (row k: sqrt(akk)); rows i < k: unused garbage
-        const float lik = d[k];
+        akk = fmaxf(akk, 1e-30f);
+        // The 64 pivots of a block are one dependent chain, and what the next pivot waits for is the update of ITS column only.  On that
+        // chain: one hardware reciprocal and the unnormalised column, A[i][c] -= a_i a_c / akk (1 ulp, like any other rounding of the
+        // update).  Off it: 1 / sqrt(akk) (v_rsq + one Newton step) for the column that is stored.  `1.f / sqrtf()` was ~25 dependent
+        // instructions per pivot (IEEE sqrt, then IEEE division): 3.2 us per 16 x 16 block, 13 of the 44 us of a blocked step.
+        const float t = d[k] * __builtin_amdgcn_rcpf(akk);
 #pragma unroll
-        for (int c = k + 1; c < PB; ++c) d[c] -= lik * lane_bcast(d[k], c);   // lane c >= k holds the valid L[c][k]
+        for (int c = k + 1; c < PB; ++c) d[c] = __builtin_fmaf(-t, lane_bcast(d[k], c), d[c]);   // lane c >= k holds the valid a_c
+        float inv = __builtin_amdgcn_rsqf(akk);
+        inv = inv * __builtin_fmaf(-0.5f * akk * inv, inv, 1.5f);
+        d[k] *= inv;                                             // rows i >= k: L[i][k] (row k: sqrt(akk)); rows i < k: unused garbage
         if (lane == 0) s_inv[o + k] = inv;
       }
       if (lane < PB) {
@@ -80,17 +91,38 @@ __device__ __forceinline__ void chol_factor_lds(float* __restrict__ Ls, float* _
     }
     __syncthreads();
     // (3) trailing lower triangle -= panel panel^T
+    // (one 4 x 4 tile of the lower triangle per thread — 78 / 36 / 10 tiles: 128 LDS reads for 256 multiply-adds; the element-per-
+    // thread form read 32 values per multiply-add chain and walked the whole square, 9 rounds at 48 rows)
     if (below > 0) {
-      for (int e = tid; e < below * below; e += 256) {
-        const int ii = e / below, jj = e - ii * below;
-        if (jj <= ii) {
-          const float* pi = Ls + (o + PB + ii) * LDS_LD + o;
-          const float* pj = Ls + (o + PB + jj) * LDS_LD + o;
-          float acc = 0.f;
+      constexpr int nt = (NBMAX - PB) / 4;                       // tiles per side at the first panel (upper bound of the search below)
+      const int ntp = below >> 2;
+      int t = tid, ti = 0;
 #pragma unroll
-          for (int k = 0; k < PB; ++k) acc = __builtin_fmaf(pi[k], pj[k], acc);
-          Ls[(o + PB + ii) * LDS_LD + o + PB + jj] -= acc;
+      for (int q = 0; q < nt; ++q)
+        if (t >= ti + 1) { t -= ti + 1; ++ti; }
+      if (ti < ntp) {                                            // tile (ti, t), t <= ti
+        const float* pi = Ls + (o + PB + 4 * ti) * LDS_LD + o;
+        const float* pj = Ls + (o + PB + 4 * t) * LDS_LD + o;
+        float acc[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[r][c] = 0.f;
+#pragma unroll
+        for (int k = 0; k < PB; ++k) {
+          float a[4], b[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { a[r] = pi[r * LDS_LD + k]; b[r] = pj[r * LDS_LD + k]; }
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[r][c] = __builtin_fmaf(a[r], b[c], acc[r][c]);
         }
+        float* cc = Ls + (o + PB + 4 * ti) * LDS_LD + o + PB + 4 * t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) cc[r * LDS_LD + c] -= acc[r][c];   // diagonal tiles also touch the strict upper triangle: unused
       }
       __syncthreads();
     }
@@ -152,10 +184,17 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(float* __restrict__ A, i
   float* Wb = W + (size_t)b * strideW;
   if (tid == 0) s_bad = 0;
   // load, identity-padded beyond nb (so partial blocks factor like full ones)
-  for (int e = tid; e < NBMAX * NBMAX; e += 256) {
-    const int r = e >> 6, c = e & 63;
-    Ls[r * LDS_LD + c] = (r < nb && c < nb) ? Ab[(size_t)r * lda + c] : (r == c ? 1.f : 0.f);
-    Ws[r * LDS_LD + c] = 0.f;
+  {
+    const int r0 = tid >> 6, c = tid & 63;
+    float av[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) av[u] = Ab[(size_t)min(r0 + 4 * u, nb - 1) * lda + min(c, nb - 1)];   // all in flight at once
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int r = r0 + 4 * u;
+      Ls[r * LDS_LD + c] = (r < nb && c < nb) ? av[u] : (r == c ? 1.f : 0.f);
+      Ws[r * LDS_LD + c] = 0.f;
+    }
   }
   __syncthreads();
 
@@ -228,18 +267,49 @@ __global__ __launch_bounds__(256) void chol_step_kernel(StepParams p) {
   }
   float* Ab = p.A + (size_t)b * p.strideA;
   const float* Wb = p.W + (size_t)b * p.strideW;
-  for (int idx = tid; idx < TS * TS; idx += 256) {                 // W^T, zero-padded beyond nb
-    const int k = idx >> 6, q = idx & 63;
-    sWT[q * TLD + k] = (k < p.nb && q < p.nb) ? Wb[(size_t)k * p.ldw + q] : 0.f;
-  }
+  // W_s and the row block's columns of this tile: element u of a thread is (row (tid >> 6) + 4 u, column tid & 63).  ALL loads of the
+  // three tiles are issued (clamped addresses, no branches) before the first one is consumed: as `for (idx ...) lds[..] = cond ?
+  // global[..] : 0` hipcc emitted one load + s_waitcnt vmcnt(0) per iteration — 32 dependent round trips, 10 of the 44 us of a step.
   const int J0 = e + J * TS, I0 = e + (I < 0 ? 0 : I) * TS;
-  for (int idx = tid; idx < TS * TS; idx += 256) {                 // the row block's columns of this tile (coalesced along c)
-    const int q = idx >> 6, c = idx & 63;
-    sJ[q * TLD + c] = (q < p.nb && J0 + c < p.ncols) ? Ab[(size_t)(p.j + q) * p.lda + J0 + c] : 0.f;
-    if (I >= 0 && I != J) sI[q * TLD + c] = (q < p.nb && I0 + c < p.n) ? Ab[(size_t)(p.j + q) * p.lda + I0 + c] : 0.f;
+  const bool two = I >= 0 && I != J;
+  const int t4r = (tid >> 4) * 4, t4c = (tid & 15) * 4;           // 4 x 4 outputs per thread
+  float aold[4][4];                                                // this tile of A: requested with the rest, needed after the three products
+  {
+    const int r0 = tid >> 6, c = tid & 63;
+    float wv[16], jv[16], iv[16];
+    const float* wp = Wb + min(c, p.nb - 1);
+    const float* jp = Ab + (size_t)p.j * p.lda + min(J0 + c, p.ncols - 1);
+    const float* ip = Ab + (size_t)p.j * p.lda + min(I0 + c, p.n - 1);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) wv[u] = wp[(size_t)min(r0 + 4 * u, p.nb - 1) * p.ldw];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) jv[u] = jp[(size_t)min(r0 + 4 * u, p.nb - 1) * p.lda];
+    if (two) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) iv[u] = ip[(size_t)min(r0 + 4 * u, p.nb - 1) * p.lda];
+    }
+    if (I >= 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)                               // clamped: out-of-range entries are never stored
+          aold[r][cc] = Ab[(size_t)min(I0 + t4r + r, p.n - 1) * p.lda + min(J0 + t4c + cc, p.ncols - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int k = r0 + 4 * u;
+      sWT[c * TLD + k] = (k < p.nb && c < p.nb) ? wv[u] : 0.f;       // W^T, zero-padded beyond nb
+      sJ[k * TLD + c] = (k < p.nb && J0 + c < p.ncols) ? jv[u] : 0.f;
+    }
+    if (two) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int k = r0 + 4 * u;
+        sI[k * TLD + c] = (k < p.nb && I0 + c < p.n) ? iv[u] : 0.f;
+      }
+    }
   }
   __syncthreads();
-  const int t4r = (tid >> 4) * 4, t4c = (tid & 15) * 4;           // 4 x 4 outputs per thread
   auto panel = [&](const float* sX, float (&out)[4][4]) {          // out = (W A_X)[t4r.., t4c..]
     f2_t acc[4][2];
 #pragma unroll
@@ -248,16 +318,6 @@ __global__ __launch_bounds__(256) void chol_step_kernel(StepParams p) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) { out[r][0] = acc[r][0][0]; out[r][1] = acc[r][0][1]; out[r][2] = acc[r][1][0]; out[r][3] = acc[r][1][1]; }
   };
-  float aold[4][4];                                                // this tile of A: requested now, needed after the three products
-  if (I >= 0) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int row = I0 + t4r + r, col = J0 + t4c + c;
-        aold[r][c] = (row < p.n && col < p.ncols) ? Ab[(size_t)row * p.lda + col] : 0.f;
-      }
-  }
   float rj[4][4], ri[4][4];
   panel(sJ, rj);
   if (I >= 0 && I != J) panel(sI, ri);
@@ -372,39 +432,49 @@ __global__ __launch_bounds__(256) void chol_subst_kernel(SubstParams p) {
   const float* Ts = Tb + (size_t)p.s * p.strideTs + (p.t_in_panel ? p.n - es : 0);
   const int c0 = c * TS;
   const int t4r = (tid >> 4) * 4, t4c = (tid & 15) * 4;
-  for (int idx = tid; idx < TS * TS; idx += 256) {
-    const int k = idx >> 6, q = idx & 63;
-    const float wv = (k < ws && q < ws) ? Wb[(size_t)k * p.ldw + q] : 0.f;
-    if (p.dir < 0) sW[k * TLD + q] = wv; else sW[q * TLD + k] = wv;   // product below sums over the FIRST index
-    sT[k * TLD + q] = (k < ws && c0 + q < p.m) ? Ts[(size_t)k * p.ldt + c0 + q] : 0.f;
-  }
-  __syncthreads();
-  // this workgroup's T_i tile and its piece of L: requested now, consumed after the first product
+  // every global load of the workgroup is issued (clamped addresses, no branches) before the first one is consumed — see chol_step_kernel
   const int ji = (i < 0 ? 0 : i) * p.nb, ei = min(ji + p.nb, p.n), wi = ei - ji;
   float* Ti = Tb + (size_t)(i < 0 ? 0 : i) * p.strideTs + (p.t_in_panel ? p.n - ei : 0);
-  float told[4][4], lpiece[16];
-  if (i >= 0) {
+  float told[4][4], lpiece[16];                                    // this workgroup's T_i tile and its piece of L: consumed after the first product
+  {
+    const int r0 = tid >> 6, q = tid & 63;
+    float wv[16], tv[16];
+    const float* wp = Wb + min(q, ws - 1);
+    const float* tp = Ts + min(c0 + q, p.m - 1);
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int u = 0; u < 16; ++u) wv[u] = wp[(size_t)min(r0 + 4 * u, ws - 1) * p.ldw];
 #pragma unroll
-      for (int cc = 0; cc < 4; ++cc)
-        told[r][cc] = (t4r + r < wi && c0 + t4c + cc < p.m) ? Ti[(size_t)(t4r + r) * p.ldt + c0 + t4c + cc] : 0.f;
-    if (p.dir < 0) {                                               // L[s, i][q][r] = panel_i[r][(js - e_i) + q]
-      const float* Pi = Rb + (size_t)i * p.strideRs;
+    for (int u = 0; u < 16; ++u) tv[u] = tp[(size_t)min(r0 + 4 * u, ws - 1) * p.ldt];
+    if (i >= 0) {
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const int idx = tid + 256 * u, r = idx >> 6, q = idx & 63;
-        lpiece[u] = (r < wi && q < ws) ? Pi[(size_t)r * p.ldr + (js - ei) + q] : 0.f;
-      }
-    } else {                                                       // L[i, s][r][q] = panel_s[q][(ji - e_s) + r]
-      const float* Ps = Rb + (size_t)p.s * p.strideRs;
+      for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const int idx = tid + 256 * u, q = idx >> 6, r = idx & 63;
-        lpiece[u] = (r < wi && q < ws) ? Ps[(size_t)q * p.ldr + (ji - es) + r] : 0.f;
+        for (int cc = 0; cc < 4; ++cc) told[r][cc] = Ti[(size_t)min(t4r + r, wi - 1) * p.ldt + min(c0 + t4c + cc, p.m - 1)];
+      if (p.dir < 0) {                                             // L[s, i][q][r] = panel_i[r][(js - e_i) + q]
+        const float* Pi = Rb + (size_t)i * p.strideRs + (js - ei) + min(q, ws - 1);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const float v = Pi[(size_t)min(r0 + 4 * u, wi - 1) * p.ldr];
+          lpiece[u] = (r0 + 4 * u < wi && q < ws) ? v : 0.f;
+        }
+      } else {                                                     // L[i, s][r][q] = panel_s[q][(ji - e_s) + r]
+        const float* Ps = Rb + (size_t)p.s * p.strideRs + (ji - es) + min(q, wi - 1);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const float v = Ps[(size_t)min(r0 + 4 * u, ws - 1) * p.ldr];
+          lpiece[u] = (q < wi && r0 + 4 * u < ws) ? v : 0.f;
+        }
       }
     }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int k = r0 + 4 * u;
+      const float w = (k < ws && q < ws) ? wv[u] : 0.f;
+      if (p.dir < 0) sW[k * TLD + q] = w; else sW[q * TLD + k] = w;   // product below sums over the FIRST index
+      sT[k * TLD + q] = (k < ws && c0 + q < p.m) ? tv[u] : 0.f;
+    }
   }
+  __syncthreads();
   f2_t x2[4][2];                                                   // X_s[q][col] = sum_k sW[k][q] T_s[k][col]
 #pragma unroll
   for (int r = 0; r < 4; ++r) x2[r][0] = x2[r][1] = f2_t{0.f, 0.f};
