@@ -37,11 +37,16 @@ struct RBParams {
   const float* bias;  // (Npad)
   int B, H, W, C, x_pitch, y_pitch;
   int tiles_x, tiles_y;
+  float inv_tiles_per_img, inv_tiles_x;   // tile id -> (b, ty, tx) without integer division (exact below 2^21 tiles: host check)
 };
 
 constexpr int XT = 16, YT = 8, HX = XT + 4, HY = YT + 4, NPOS = HX * HY;
 
-template <typename T, int KP>
+// PKC: the real 16-byte packets per pixel as a compile-time constant (0: run-time p.C / 8).  The tile staging and the store loop turn
+// a linear index into (position, packet) and (row, column) for every 16-byte access; with a run-time divisor each of those is a ~35-
+// instruction sequence, and at D = 24 (PKC = 3, the two finest refiners, 18 launches per match) those divisions were as many
+// instructions as the 400 multiply-adds of a tile.
+template <typename T, int KP, int PKC>
 __global__ __launch_bounds__(256, 1) void refiner_block_kernel(RBParams p) {
   constexpr int KPAD = 32 * KP;            // padded channel count (inputs of the 1x1)
   constexpr int NT = KPAD / 16;            // 16-wide output tiles (outputs are padded to KPAD as well)
@@ -56,9 +61,17 @@ __global__ __launch_bounds__(256, 1) void refiner_block_kernel(RBParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int m = lane & 15, kq = lane >> 4;
-  const int PKT = p.C / 8;                                      // real packets per pixel
+  const int PKT = PKC ? PKC : p.C / 8;                          // real packets per pixel
   const T* x = static_cast<const T*>(p.x);
   T* y = static_cast<T*>(p.y);
+  const int tiles_per_img = p.tiles_x * p.tiles_y;
+  auto tile_origin = [&](int tile, int& b, int& ty0, int& tx0) {
+    b = (int)(((float)tile + 0.5f) * p.inv_tiles_per_img);
+    const int tt = tile - b * tiles_per_img;
+    const int tyi = (int)(((float)tt + 0.5f) * p.inv_tiles_x);
+    ty0 = tyi * YT;
+    tx0 = (tt - tyi * p.tiles_x) * XT;
+  };
 
   // ---- once per workgroup: weights and constants ----
   for (int i = tid; i < KPAD * (KPAD / 8); i += 256) {
@@ -73,15 +86,14 @@ __global__ __launch_bounds__(256, 1) void refiner_block_kernel(RBParams p) {
   }
   // channel padding of the input tile (packets PKT .. KPAD/8-1) stays zero for the whole kernel
   const int ntile = p.tiles_x * p.tiles_y * p.B;
-  constexpr int NLD = (NPOS * (KPAD / 8) + 255) / 256;          // 16-byte loads per thread and tile (upper bound)
+  constexpr int NLD = (NPOS * (PKC ? PKC : KPAD / 8) + 255) / 256;   // 16-byte loads per thread and tile (upper bound)
   const int nload = NPOS * PKT;
   u32x4 pre[NLD];
   // The next tile's input is fetched into registers while the current one is computed (one workgroup per CU at
   // KPAD = 160: nothing else would hide the HBM latency).  Out-of-image taps become zeros (the conv's padding).
   auto fetch = [&](int tile) {
-    const int b = tile / (p.tiles_x * p.tiles_y);
-    const int tt = tile - b * (p.tiles_x * p.tiles_y);
-    const int ty0 = (tt / p.tiles_x) * YT, tx0 = (tt % p.tiles_x) * XT;
+    int b, ty0, tx0;
+    tile_origin(tile, b, ty0, tx0);
     const T* xb = x + (size_t)b * p.H * p.W * p.x_pitch;
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
@@ -102,9 +114,8 @@ __global__ __launch_bounds__(256, 1) void refiner_block_kernel(RBParams p) {
   }
   if ((int)blockIdx.x < ntile) fetch(blockIdx.x);
   for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
-    const int b = tile / (p.tiles_x * p.tiles_y);
-    const int tt = tile - b * (p.tiles_x * p.tiles_y);
-    const int ty0 = (tt / p.tiles_x) * YT, tx0 = (tt % p.tiles_x) * XT;
+    int b, ty0, tx0;
+    tile_origin(tile, b, ty0, tx0);
     __syncthreads();                                            // previous tile's stores have read s_out
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
@@ -190,17 +201,26 @@ __global__ __launch_bounds__(256, 1) void refiner_block_kernel(RBParams p) {
   }
 }
 
-template <typename T, int KP>
-int launch_rb(const RBParams& p, hipStream_t s) {
+template <typename T, int KP, int PKC>
+int launch_rb(RBParams p, hipStream_t s) {
   constexpr int KPAD = 32 * KP, RS = KPAD / 8 + 1;
   const size_t smem = (size_t)(NPOS * RS + KPAD * RS + 25 * (KPAD / 8)) * 16 + 3 * KPAD * 4;
   static std::atomic<uint64_t> attr_done{0};
-  if (int rc = ensure_dyn_smem(reinterpret_cast<const void*>(refiner_block_kernel<T, KP>), (int)smem, attr_done, "roma_refiner_block")) return rc;
-  const int ntile = p.B * p.tiles_x * p.tiles_y;
+  if (int rc = ensure_dyn_smem(reinterpret_cast<const void*>(refiner_block_kernel<T, KP, PKC>), (int)smem, attr_done, "roma_refiner_block")) return rc;
+  const long ntile = (long)p.B * p.tiles_x * p.tiles_y;
+  ROMA_REQUIRE(ntile < (1 << 21), ROMA_E_SHAPE, "roma_refiner_block: %ld tiles in one launch (< 2^21)", ntile);
+  p.inv_tiles_per_img = 1.0f / (float)(p.tiles_x * p.tiles_y);
+  p.inv_tiles_x = 1.0f / (float)p.tiles_x;
   const int per_cu = KP == 1 ? 4 : 1;                          // LDS footprint: ~25 KB (KP=1) or ~140 KB (KP=5)
-  const int grid = ntile < 256 * per_cu ? ntile : 256 * per_cu;
-  hipLaunchKernelGGL((refiner_block_kernel<T, KP>), dim3(grid), dim3(256), smem, s, p);
+  const int grid = ntile < 256 * per_cu ? (int)ntile : 256 * per_cu;
+  hipLaunchKernelGGL((refiner_block_kernel<T, KP, PKC>), dim3(grid), dim3(256), smem, s, p);
   ROMA_CHECK_LAUNCH();
+}
+
+template <typename T>
+int launch_rb_any(const RBParams& p, int kpad, hipStream_t s) {
+  if (kpad == 32) return p.C == 24 ? launch_rb<T, 1, 3>(p, s) : launch_rb<T, 1, 0>(p, s);
+  return launch_rb<T, 5, 0>(p, s);
 }
 
 
@@ -295,10 +315,9 @@ extern "C" int roma_refiner_block(const void* x, const void* w25, const float* s
   ROMA_REQUIRE((kpad == 32 || kpad == 160) && C <= kpad && C % 8 == 0, ROMA_E_UNSUPPORTED, "roma_refiner_block: C=%d, kpad=%d (kpad must be 32 or 160, C a multiple of 8)", C, kpad);
   ROMA_REQUIRE(x_pitch % 8 == 0 && y_pitch % 8 == 0 && aligned16(x) && aligned16(y) && aligned16(w25) && aligned16(wt), ROMA_E_ALIGN,
                "roma_refiner_block: pitches must be multiples of 8 and bases 16-byte aligned");
-  RBParams p{x, y, w25, wt, scale, shift, bias, B, H, W, C, x_pitch, y_pitch, (W + XT - 1) / XT, (H + YT - 1) / YT};
+  RBParams p{x, y, w25, wt, scale, shift, bias, B, H, W, C, x_pitch, y_pitch, (W + XT - 1) / XT, (H + YT - 1) / YT, 0.f, 0.f};
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (dtype == ROMA_F16) return kpad == 32 ? launch_rb<half_t, 1>(p, s) : launch_rb<half_t, 5>(p, s);
-  return kpad == 32 ? launch_rb<bf16_t, 1>(p, s) : launch_rb<bf16_t, 5>(p, s);
+  return dtype == ROMA_F16 ? launch_rb_any<half_t>(p, kpad, s) : launch_rb_any<bf16_t>(p, kpad, s);
 }
 
 extern "C" int roma_pointwise_mfma(const void* x, const void* wt, const float* bias, void* y, long M, int C, int kpad, int dtype,

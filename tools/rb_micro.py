@@ -9,3 +9,9 @@ sc = torch.ones(kpad, device="cuda"); sh = torch.zeros(kpad, device="cuda"); b =
 out = torch.empty_like(x)
 for _ in range(5): ops.refiner_block(x, w25, sc, sh, wt, b, C, out=out)
 torch.cuda.synchronize(); print("done")
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(50): ops.refiner_block(x, w25, sc, sh, wt, b, C, out=out)
+e1.record(); torch.cuda.synchronize()
+t = e0.elapsed_time(e1) / 50 * 1e-3
+print(f"refiner_block C={C} h={h}: {t*1e6:.1f} us  {2 * x.numel() * 2 / t / 1e12:.2f} TB/s in+out")
