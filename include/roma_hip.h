@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ROMA_ABI_VERSION 3
+#define ROMA_ABI_VERSION 4
 
 enum { ROMA_F32 = 0, ROMA_F16 = 1, ROMA_BF16 = 2 };
 enum { ROMA_NCHW = 0, ROMA_NHWC = 1 };
@@ -213,10 +213,14 @@ int roma_refiner_block(const void* x, const void* w25, const float* scale, const
 /* The same block at D = 576 (the scale-4 refiner), fp16, as ONE kernel: a 128-pixel x 576-channel output tile per workgroup, the
  * depthwise result computed once per pixel and fed to the matrix cores through LDS, the 1x1 weights streamed panel by panel.
  * matcher.py:77-103, 139-140.  x, y: (B,H,W,pitch) channels-last fp16 (must not alias); w25p: the depthwise taps in fp16 (the
- * reference's autocast convolution weights), panel-major [D/32][25][4][8] (tap t of channel c at [c/32][t][(c%32)/8][c%8]); scale,
- * shift, bias: (D) fp32; wp: the Conv2d(D, D, 1) weight [out][in] re-tiled by roma_refiner_wide_pack (a HOST function: both
- * pointers in host memory, D*D 16-bit elements each). */
+ * reference's autocast convolution weights) as laid out by roma_refiner_wide_taps; scale, shift, bias: (D) fp32; wp: the
+ * Conv2d(D, D, 1) weight [out][in] re-tiled by roma_refiner_wide_pack.  Both packers are HOST functions (all pointers in host memory):
+ *   roma_refiner_wide_pack: wt, wp: D*D 16-bit elements each;
+ *   roma_refiner_wide_taps: w25 (25, D) tap-major 16-bit -> w25p, 60*D elements: [D/32 panels][5 tap rows][4 packets][2 half-packets]
+ *     [6 pair sets][4 channels][2] — the kernel multiplies horizontally adjacent PIXEL PAIRS with tap pairs (v_dot2_f32_f16): of a tap
+ *     row (w0..w4) the even output column takes (w0,w1) (w2,w3) (w4,0), the odd one (0,w0) (w1,w2) (w3,w4). */
 int roma_refiner_wide_pack(const void* wt, void* wp, int D);
+int roma_refiner_wide_taps(const void* w25, void* w25p, int D);
 int roma_refiner_block_wide(const void* x, const void* w25p, const float* scale, const float* shift, const void* wp,
                             const float* bias, void* y, int B, int H, int W, int D, int x_pitch, int y_pitch, int dtype,
                             void* stream);

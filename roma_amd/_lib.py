@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libroma_hip.so")
 ROMA_F32, ROMA_F16, ROMA_BF16 = 0, 1, 2
 ROMA_NCHW, ROMA_NHWC = 0, 1
 LC_VARIANTS = {"auto": 0, "tile8x4": 1, "tile8x8": 2, "rows8": 3}
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # name -> argtypes; restype is c_int unless listed in _RESTYPES.  Mirrors include/roma_hip.h one to one.
 SIGNATURES = {
@@ -50,6 +50,7 @@ SIGNATURES = {
     "roma_refiner_block": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                            c_int, c_int, c_void_p],
     "roma_refiner_wide_pack": [c_void_p, c_void_p, c_int],
+    "roma_refiner_wide_taps": [c_void_p, c_void_p, c_int],
     "roma_refiner_block_wide": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                 c_int, c_void_p],
     "roma_refiner_head": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -12,8 +12,13 @@
 //
 // Workgroup = 512 threads, tile = 16 x 8 pixels, K-panels of 32 channels.  Per panel:
 //   depthwise (VALU): wave w owns channel packet kq = w & 3 of 64 pixels; the panel's input halo lives in LDS as four packet
-//     PLANES [kq][12 rows][32-pixel pitch] (pitch 32: the 64 consecutive-pixel ds_read_b128 of a tap are conflict-free), the taps
-//     are wave-uniform (scalar loads), fp32 accumulate (v_fma_mix_f32), BN + ReLU, the packed result goes to t[pixel][64 B];
+//     PLANES [kq][12 rows][16 pixel PAIRS][2 half-packets][16 B], a word = one channel of two horizontally adjacent pixels, so that
+//     v_dot2_f32_f16 takes two taps per instruction: a lane owns an (even, odd) pixel pair x 4 channels, and both outputs use the same
+//     three pair words per tap row — even: (w0,w1).E0 + (w2,w3).E1 + (w4,0).E2, odd: (0,w0).E0 + (w1,w2).E1 + (w3,w4).E2 — 15
+//     instructions per output instead of the 25 v_fma_mix of the first version (both forms issue at ~4.2 cycles per SIMD:
+//     profiles/r03_valu_rates.txt).  The interleave is two v_perm per word when the loader writes the halo; the six tap pairs per
+//     channel come pre-packed from the host (roma_refiner_wide_taps), staged in LDS with the halo; BN + ReLU, the packed result
+//     goes to t[pixel][64 B];
 //   1x1 (MFMA, operands swapped so that a lane ends up with 4 consecutive output channels of one pixel): wave (mh, nq) multiplies
 //     N-blocks 9 nq .. 9 nq + 8 (A = weight rows, read from the LDS panel) with M-blocks 4 mh .. 4 mh + 3 (B = t rows);
 //   t and the weight panel are [row][64 B] with the packet index XOR-ed by (row >> 1) & 3: conflict-free fragment reads.
@@ -31,7 +36,7 @@ using lc::mfma16r;
 struct RWParams {
   const void* x;
   void* y;
-  const void* w25p;    // depthwise taps, T, panel-major: [D/32][25 taps][4 packets][8 channels]
+  const void* w25p;    // depthwise taps, T, as pairs: [D/32][5 tap rows][4 packets][2 half-packets][6 pair sets][4 channels][2]: sets (w0,w1) (w2,w3) (w4,0) (0,w0) (w1,w2) (w3,w4) of tap row (w0..w4)
   const void* wp;      // panel-major 1x1 weights: [D/32][D out rows][64 B], packets swizzled (see roma_refiner_wide_pack)
   const float* scale;  // (D) folded BN
   const float* shift;  // (D)
@@ -47,19 +52,20 @@ struct RWParams {
 typedef const __attribute__((address_space(4))) float cfloat;
 __device__ __forceinline__ cfloat* as_const(const float* p) { return (cfloat*)(uintptr_t)p; }
 
-constexpr int TW = 16, TH = 8, HXW = TW + 4, HYH = TH + 4, HP = 32;
-constexpr int PLANE = HYH * HP * 16 + 16;                       // bytes of one packet plane (+16: the four planes start on different banks)
+constexpr int TW = 16, TH = 8, HXW = TW + 4, HYH = TH + 4, HPR = 16;   // HPR: pixel pairs per plane row (10 used; 512-byte rows)
+constexpr int PLANE = HYH * HPR * 32 + 16;                      // bytes of one packet plane (+16: the four planes start on different banks)
+constexpr int NTAPV = 5 * 4 * 2 * 6;                            // 16-byte tap vectors per panel
 
 template <typename T, int D>
 __global__ __launch_bounds__(512, 1) void refiner_wide_kernel(RWParams p) {
   constexpr int NKP = D / 32, NB = D / 16, NBW = NB / 4, MBW = 4;
-  constexpr int WBUF = D * 64, XBUF = 4 * PLANE, TBUF = TW * TH * 64, DWBUF = 25 * 4 * 16;
+  constexpr int WBUF = D * 64, XBUF = 4 * PLANE, TBUF = TW * TH * 64, DWBUF = NTAPV * 16;
   static_assert(NB % 4 == 0 && 2 * (WBUF + XBUF + TBUF + DWBUF) <= 160 * 1024, "tile does not fit");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* s_w = smem;                                    // [2][D][64 B]
   unsigned char* s_x = s_w + 2 * WBUF;                          // [2][4 planes]
   unsigned char* s_t = s_x + 2 * XBUF;                          // [2][128 pixels][64 B]
-  unsigned char* s_dw = s_t + 2 * TBUF;                         // [2][25 taps][4 packets][16 B]
+  unsigned char* s_dw = s_t + 2 * TBUF;                         // [2][5 tap rows][4 packets][2 halves][6 sets][16 B]
   const uint32_t lds_w = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)s_w;
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -70,34 +76,43 @@ __global__ __launch_bounds__(512, 1) void refiner_wide_kernel(RWParams p) {
   const T* xb = static_cast<const T*>(p.x) + (size_t)b * p.H * p.W * p.x_pitch;
   T* yb = static_cast<T*>(p.y) + (size_t)b * p.H * p.W * p.y_pitch;
 
-  // ---- loader role: two (halo pixel, packet) items per thread ----
-  uint32_t xsrc[2], xdst[2];
-  bool xok[2], xuse[2];
+  // ---- loader role: one (halo pixel PAIR, packet) item per thread: 12 rows x 10 pairs x 4 packets = 480 of the 512 threads ----
+  uint32_t xsrc[2], xdst;
+  bool xok[2], xuse;
+  {
+    const int pr = min(tid >> 2, (HXW / 2) * HYH - 1), kql = tid & 3;
+    const int hy = pr / (HXW / 2), jj = pr - hy * (HXW / 2);
+    const int yy = ty0 - 2 + hy;
+    xuse = tid < 4 * (HXW / 2) * HYH;
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int j = tid + 512 * s;
-    const int pos = min(j >> 2, HXW * HYH - 1), kq = j & 3;
-    const int hy = pos / HXW, hx = pos - hy * HXW;
-    const int yy = ty0 - 2 + hy, xx = tx0 - 2 + hx;
-    xuse[s] = j < 4 * HXW * HYH;
-    xok[s] = xuse[s] && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
-    xsrc[s] = (uint32_t)((min(max(yy, 0), p.H - 1) * p.W + min(max(xx, 0), p.W - 1)) * p.x_pitch + kq * 8);
-    xdst[s] = (uint32_t)(kq * PLANE + (hy * HP + hx) * 16);
+    for (int s = 0; s < 2; ++s) {
+      const int xx = tx0 - 2 + 2 * jj + s;
+      xok[s] = xuse && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+      xsrc[s] = (uint32_t)((min(max(yy, 0), p.H - 1) * p.W + min(max(xx, 0), p.W - 1)) * p.x_pitch + kql * 8);
+    }
+    xdst = (uint32_t)(kql * PLANE + (hy * HPR + jj) * 32);
   }
   // the halo (and taps) of panel kp + 2 are requested at the start of phase kp and written to LDS at its end
   u32x4 xreg[2], dwreg;
   auto load_x = [&](int kp) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) xreg[s] = *reinterpret_cast<const u32x4*>(xb + xsrc[s] + kp * 32);
-    if (tid < 100) dwreg = reinterpret_cast<const u32x4*>(p.w25p)[kp * 100 + tid];     // that panel's taps
+    if (tid < NTAPV) dwreg = reinterpret_cast<const u32x4*>(p.w25p)[kp * NTAPV + tid];     // that panel's tap pairs
   };
   // (the zero padding of out-of-image halo pixels is applied HERE, a phase after the request: a select right behind the load made
   // every wave wait for its HBM miss at the start of the phase — 32 us of the first version's 191)
   auto store_x = [&](int buf) {
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-      if (xuse[s]) *reinterpret_cast<u32x4*>(s_x + buf * XBUF + xdst[s]) = xok[s] ? xreg[s] : u32x4{0, 0, 0, 0};
-    if (tid < 100) *reinterpret_cast<u32x4*>(s_dw + buf * DWBUF + tid * 16) = dwreg;
+    if (xuse) {
+      const u32x4 a = xok[0] ? xreg[0] : u32x4{0, 0, 0, 0}, c = xok[1] ? xreg[1] : u32x4{0, 0, 0, 0};
+      u32x4 lo, hi;                                             // word = (channel @ even pixel, channel @ odd pixel)
+      lo[0] = __builtin_amdgcn_perm(c[0], a[0], 0x05040100u); lo[1] = __builtin_amdgcn_perm(c[0], a[0], 0x07060302u);
+      lo[2] = __builtin_amdgcn_perm(c[1], a[1], 0x05040100u); lo[3] = __builtin_amdgcn_perm(c[1], a[1], 0x07060302u);
+      hi[0] = __builtin_amdgcn_perm(c[2], a[2], 0x05040100u); hi[1] = __builtin_amdgcn_perm(c[2], a[2], 0x07060302u);
+      hi[2] = __builtin_amdgcn_perm(c[3], a[3], 0x05040100u); hi[3] = __builtin_amdgcn_perm(c[3], a[3], 0x07060302u);
+      *reinterpret_cast<u32x4*>(s_x + buf * XBUF + xdst) = lo;
+      *reinterpret_cast<u32x4*>(s_x + buf * XBUF + xdst + 16) = hi;
+    }
+    if (tid < NTAPV) *reinterpret_cast<u32x4*>(s_dw + buf * DWBUF + tid * 16) = dwreg;
   };
   // the weight panel: WBUF / 1024 = 36 wave-instructions, instruction ii = 8 k + wave
   auto dma_w = [&](int kp, int buf) {
@@ -109,11 +124,13 @@ __global__ __launch_bounds__(512, 1) void refiner_wide_kernel(RWParams p) {
     }
   };
 
-  // ---- depthwise role ----
+  // ---- depthwise role: lane = (tile row, pixel pair, half-packet) ----
   const int kq = wave & 3;
-  const int pl = (wave >> 2) * 64 + lane;                        // pixel of the tile: row pl >> 4, column pl & 15
-  const uint32_t xrd = (uint32_t)(kq * PLANE + ((pl >> 4) * HP + (pl & 15)) * 16);
-  const uint32_t twr = (uint32_t)(pl * 64 + ((kq ^ ((pl >> 1) & 3)) << 4));
+  const int hsel = lane & 1, jp = (lane >> 1) & 7;
+  const int prow = (wave >> 2) * 4 + (lane >> 4);                // tile row
+  const int ple = prow * 16 + 2 * jp;                            // the even pixel of the pair (the odd one is ple + 1: same swizzle)
+  const uint32_t xrd = (uint32_t)(kq * PLANE + ((prow * HPR + jp) * 2 + hsel) * 16);
+  const uint32_t twr = (uint32_t)(ple * 64 + ((kq ^ ((ple >> 1) & 3)) << 4) + hsel * 8);
   // ---- MFMA role ----
   const int n16 = lane & 15, kg = lane >> 4;
   const int mh = wave & 1, nq = wave >> 1;
@@ -127,39 +144,48 @@ __global__ __launch_bounds__(512, 1) void refiner_wide_kernel(RWParams p) {
   // depthwise 5x5 + BN + ReLU of panel kp: this wave's packet, 64 pixels; X / taps buffer `buf` -> t buffer `buf`
   auto dw_panel = [&](int kp, int buf) {
     const int c0 = __builtin_amdgcn_readfirstlane(kp * 32 + kq * 8);
-    const unsigned char* wts = s_dw + buf * DWBUF + kq * 16;
-    float a8[8];
+    const unsigned char* wts = s_dw + buf * DWBUF + (kq * 2 + hsel) * 96;
+    float ae[4], ao[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) a8[e] = 0.f;
+    for (int e = 0; e < 4; ++e) ae[e] = ao[e] = 0.f;
     const unsigned char* xs = s_x + buf * XBUF + xrd;
-    // one row of taps at a time: its ten LDS reads are all issued before the row's 40 multiply-adds (the SIMD partner runs MFMAs
-    // meanwhile, so nothing else hides this wave's LDS latency: one exposed LDS round trip per row instead of one per tap)
+    // one row of taps at a time: its nine LDS reads are all issued before the row's 24 dot products (the SIMD partner runs MFMAs
+    // meanwhile, so nothing else hides this wave's LDS latency: one exposed LDS round trip per row)
 #pragma unroll
     for (int dy = 0; dy < 5; ++dy) {
-      u32x4 xv[5], wv[5];
+      u32x4 ev[3], tv[6];
 #pragma unroll
-      for (int dx = 0; dx < 5; ++dx) {
-        xv[dx] = *reinterpret_cast<const u32x4*>(xs + (dy * HP + dx) * 16);
-        wv[dx] = *reinterpret_cast<const u32x4*>(wts + (dy * 5 + dx) * 64);           // one address per wave: an LDS broadcast
-      }
+      for (int k = 0; k < 3; ++k) ev[k] = *reinterpret_cast<const u32x4*>(xs + (dy * HPR + k) * 32);
+#pragma unroll
+      for (int q = 0; q < 6; ++q) tv[q] = *reinterpret_cast<const u32x4*>(wts + dy * (4 * 2 * 96) + q * 16);   // two addresses per wave
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int dx = 0; dx < 5; ++dx)
+      for (int k = 0; k < 3; ++k)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const uint32_t u = xv[dx][e], uw = wv[dx][e];
-          const half2_t h = __builtin_bit_cast(half2_t, u), hw = __builtin_bit_cast(half2_t, uw);
-          a8[2 * e] = __builtin_fmaf((float)h[0], (float)hw[0], a8[2 * e]);
-          a8[2 * e + 1] = __builtin_fmaf((float)h[1], (float)hw[1], a8[2 * e + 1]);
+          const half2_t xe = __builtin_bit_cast(half2_t, (uint32_t)ev[k][e]);
+          ae[e] = __builtin_amdgcn_fdot2(xe, __builtin_bit_cast(half2_t, (uint32_t)tv[k][e]), ae[e], false);
+          ao[e] = __builtin_amdgcn_fdot2(xe, __builtin_bit_cast(half2_t, (uint32_t)tv[3 + k][e]), ao[e], false);
         }
       __builtin_amdgcn_sched_barrier(0);
     }
     cfloat* sc = as_const(p.scale) + c0;
     cfloat* sh = as_const(p.shift) + c0;
-    float r8[8];
+    uint32_t oe[2], oo[2];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) r8[e] = fmaxf(__builtin_fmaf(a8[e], sc[e], sh[e]), 0.f);
-    *reinterpret_cast<u32x4*>(s_t + buf * TBUF + twr) = pack16<T>(r8);
+    for (int e = 0; e < 4; e += 2) {
+      float re[2], ro[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float scv = hsel ? sc[4 + e + i] : sc[e + i], shv = hsel ? sh[4 + e + i] : sh[e + i];
+        re[i] = fmaxf(__builtin_fmaf(ae[e + i], scv, shv), 0.f);
+        ro[i] = fmaxf(__builtin_fmaf(ao[e + i], scv, shv), 0.f);
+      }
+      oe[e >> 1] = __builtin_bit_cast(uint32_t, half2_t{(half_t)re[0], (half_t)re[1]});
+      oo[e >> 1] = __builtin_bit_cast(uint32_t, half2_t{(half_t)ro[0], (half_t)ro[1]});
+    }
+    *reinterpret_cast<uint2*>(s_t + buf * TBUF + twr) = uint2{oe[0], oe[1]};
+    *reinterpret_cast<uint2*>(s_t + buf * TBUF + twr + 64) = uint2{oo[0], oo[1]};
   };
   // 1x1 of panel kp on the matrix cores: 9 weight fragments x 4 pixel fragments out of t / weight buffers `buf`
   auto mfma_panel = [&](int buf) {
@@ -258,6 +284,28 @@ extern "C" int roma_refiner_wide_pack(const void* wt, void* wp, int D) {
   return 0;
 }
 
+// Host-side helper: w25 (25, D) tap-major 16-bit -> the pair layout of RWParams::w25p (60 D elements).  Both pointers in host memory.
+extern "C" int roma_refiner_wide_taps(const void* w25, void* w25p, int D) {
+  ROMA_REQUIRE(w25 && w25p, ROMA_E_ARG, "roma_refiner_wide_taps: null pointer");
+  ROMA_REQUIRE(D > 0 && D % 32 == 0, ROMA_E_SHAPE, "roma_refiner_wide_taps: D = %d must be a multiple of 32", D);
+  const uint16_t* src = static_cast<const uint16_t*>(w25);
+  uint16_t* dst = static_cast<uint16_t*>(w25p);
+  // pair set -> (tap column of the low half, of the high half); -1: zero.  Sets 0-2: even output column, 3-5: odd output column.
+  static const int lo[6] = {0, 2, 4, -1, 1, 3}, hi[6] = {1, 3, -1, 0, 2, 4};
+  size_t o = 0;
+  for (int kp = 0; kp < D / 32; ++kp)
+    for (int dy = 0; dy < 5; ++dy)
+      for (int kq = 0; kq < 4; ++kq)
+        for (int h = 0; h < 2; ++h)
+          for (int st = 0; st < 6; ++st)
+            for (int ch = 0; ch < 4; ++ch) {
+              const int c = kp * 32 + kq * 8 + h * 4 + ch;
+              dst[o++] = lo[st] < 0 ? (uint16_t)0 : src[(size_t)(dy * 5 + lo[st]) * D + c];
+              dst[o++] = hi[st] < 0 ? (uint16_t)0 : src[(size_t)(dy * 5 + hi[st]) * D + c];
+            }
+  return 0;
+}
+
 extern "C" int roma_refiner_block_wide(const void* x, const void* w25p, const float* scale, const float* shift, const void* wp,
                                        const float* bias, void* y, int B, int H, int W, int D, int x_pitch, int y_pitch, int dtype,
                                        void* stream) {
@@ -268,7 +316,7 @@ extern "C" int roma_refiner_block_wide(const void* x, const void* w25p, const fl
                aligned16(y) && y_pitch % 8 == 0 && aligned16(bias), ROMA_E_ALIGN, "roma_refiner_block_wide: pitch / alignment");
   ROMA_REQUIRE((size_t)H * W * x_pitch < (1ull << 31), ROMA_E_SHAPE, "roma_refiner_block_wide: map too large for 32-bit offsets");
   RWParams p{x, y, w25p, wp, scale, shift, bias, B, H, W, x_pitch, y_pitch, (W + TW - 1) / TW, (H + TH - 1) / TH};
-  constexpr int smem_loop = 2 * (576 * 64 + 4 * PLANE + TW * TH * 64 + 25 * 4 * 16), smem_out = TW * TH * (576 * 2 + 16);
+  constexpr int smem_loop = 2 * (576 * 64 + 4 * PLANE + TW * TH * 64 + NTAPV * 16), smem_out = TW * TH * (576 * 2 + 16);
   constexpr int smem = smem_loop > smem_out ? smem_loop : smem_out;
   static std::atomic<uint64_t> attr_done{0};
   if (int rc = ensure_dyn_smem(reinterpret_cast<const void*>(refiner_wide_kernel<half_t, 576>), smem, attr_done, "roma_refiner_block_wide")) return rc;

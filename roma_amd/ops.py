@@ -603,9 +603,16 @@ def refiner_wide_pack(wt_out_in):
 
 
 def refiner_wide_taps(w25, dtype=torch.float16):
-    """(25, D) tap-major depthwise weights -> the panel-major 16-bit layout roma_refiner_block_wide stages: [D/32][25][4][8]."""
+    """(25, D) tap-major depthwise weights -> the 16-bit layout roma_refiner_block_wide stages (host-side helper of the library,
+    include/roma_hip.h): [D/32 panels][5 tap rows][4 packets][2 half-packets][6 pair sets][4 channels][2].  The kernel multiplies
+    pixel PAIRS (even, odd column) with tap pairs (v_dot2_f32_f16): for a tap row (w0..w4) the even output takes (w0,w1) (w2,w3)
+    (w4,0) and the odd one (0,w0) (w1,w2) (w3,w4) against the same three pair words."""
     D = w25.shape[1]
-    return w25.reshape(25, D // 32, 4, 8).permute(1, 0, 2, 3).contiguous().to(dtype)
+    w = w25.detach().to("cpu").to(dtype).contiguous()
+    assert w.shape == (25, D) and w.element_size() == 2
+    out = torch.empty((D // 32, 5, 4, 2, 6, 4, 2), dtype=dtype)
+    check(_lib.load().roma_refiner_wide_taps(w.data_ptr(), out.data_ptr(), D), "roma_refiner_wide_taps")
+    return out.to(w25.device)
 
 
 def refiner_block_wide(x_nhwc, w25p, scale, shift, wp, bias, out=None):
@@ -613,7 +620,7 @@ def refiner_block_wide(x_nhwc, w25p, scale, shift, wp, bias, out=None):
     scale / shift / bias (576) fp32, wp from refiner_wide_pack.  out must not alias x."""
     _need_gpu(x_nhwc, w25p, scale, shift, wp, bias, out)
     B, H, W, D = x_nhwc.shape
-    assert x_nhwc.is_contiguous() and w25p.shape == (D // 32, 25, 4, 8) and w25p.dtype == x_nhwc.dtype and w25p.is_contiguous()
+    assert x_nhwc.is_contiguous() and w25p.shape == (D // 32, 5, 4, 2, 6, 4, 2) and w25p.dtype == x_nhwc.dtype and w25p.is_contiguous()
     assert all(t.dtype == torch.float32 and t.numel() == D and t.is_contiguous() for t in (scale, shift, bias))
     if out is None:
         out = torch.empty_like(x_nhwc)
