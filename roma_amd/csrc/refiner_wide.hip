@@ -114,8 +114,12 @@ __global__ __launch_bounds__(512, 1) void refiner_wide_kernel(RWParams p) {
     }
     if (tid < NTAPV) *reinterpret_cast<u32x4*>(s_dw + buf * DWBUF + tid * 16) = dwreg;
   };
-  // the weight panel: WBUF / 1024 = 36 wave-instructions, instruction ii = 8 k + wave
-  auto dma_w = [&](int kp, int buf) {
+  // the weight panel: WBUF / 1024 = 36 wave-instructions (1 KB each).  Prologue: all eight waves share them.  Inside a phase they are
+  // issued by waves 0-3 ONE AT A TIME between the nine MFMA blocks of their 1x1 half (mfma_panel): issued together at the start of
+  // the phase, 36 KB of DMA + the halo loads kept the vector-memory issue of all eight waves blocked for ~900 of the phase's 5800
+  // cycles (tools/scratch/rw_prof: two plain loads took a depthwise-first wave 1000 cycles to issue), and those waves — whose LDS
+  // reads then ran against the landing weights — were the critical path while waves 0-3 idled ~1100 cycles at the barrier.
+  auto dma_w_all = [&](int kp, int buf) {
     const unsigned char* src = static_cast<const unsigned char*>(p.wp) + (size_t)kp * WBUF;
 #pragma unroll
     for (int k = 0; k < (WBUF / 1024 + 7) / 8; ++k) {
@@ -123,7 +127,6 @@ __global__ __launch_bounds__(512, 1) void refiner_wide_kernel(RWParams p) {
       if (ii < WBUF / 1024) lc::dma16_so(src, (uint32_t)(ii * 1024 + lane * 16), lds_w + (uint32_t)(buf * WBUF + ii * 1024));
     }
   };
-
   // ---- depthwise role: lane = (tile row, pixel pair, half-packet) ----
   const int kq = wave & 3;
   const int hsel = lane & 1, jp = (lane >> 1) & 7;
@@ -188,14 +191,21 @@ __global__ __launch_bounds__(512, 1) void refiner_wide_kernel(RWParams p) {
     *reinterpret_cast<uint2*>(s_t + buf * TBUF + twr + 64) = uint2{oo[0], oo[1]};
   };
   // 1x1 of panel kp on the matrix cores: 9 weight fragments x 4 pixel fragments out of t / weight buffers `buf`
-  auto mfma_panel = [&](int buf) {
+  // (kpn >= 0: this wave also streams its share of panel kpn's weights into the other weight buffer, one DMA per block)
+  static_assert(4 * NBW == WBUF / 1024, "one weight DMA per wave 0-3 and MFMA block");
+  auto mfma_panel = [&](int buf, int kpn) {
     const unsigned char* tb = s_t + buf * TBUF + mh * (MBW * 1024) + fo;
     const unsigned char* wb = s_w + buf * WBUF + nq * (NBW * 1024) + fo;
+    const unsigned char* src = static_cast<const unsigned char*>(p.wp) + (size_t)max(kpn, 0) * WBUF;
     u32x4 bt[MBW];
 #pragma unroll
     for (int mb = 0; mb < MBW; ++mb) bt[mb] = *reinterpret_cast<const u32x4*>(tb + mb * 1024);
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb) {
+      if (kpn >= 0) {
+        const int ii = nb * 4 + wave;
+        lc::dma16_so(src, (uint32_t)(ii * 1024 + lane * 16), lds_w + (uint32_t)((buf ^ 1) * WBUF + ii * 1024));
+      }
       const u32x4 aw = *reinterpret_cast<const u32x4*>(wb + nb * 1024);
 #pragma unroll
       for (int mb = 0; mb < MBW; ++mb) acc[nb][mb] = mfma16r(aw, bt[mb], acc[nb][mb], T{});
@@ -203,7 +213,7 @@ __global__ __launch_bounds__(512, 1) void refiner_wide_kernel(RWParams p) {
   };
 
   // ---- prologue: weights 0, halo 0 -> t 0; halo 1 in LDS; halo 2 requested ----
-  dma_w(0, 0);
+  dma_w_all(0, 0);
   load_x(0);
   store_x(0);
   if (NKP > 1) load_x(1);
@@ -217,12 +227,11 @@ __global__ __launch_bounds__(512, 1) void refiner_wide_kernel(RWParams p) {
   // depthwise 63 us + 1x1 39 us + loads 41 us + skeleton 56 us added up exactly: nothing overlapped).
   auto phase = [&](int kp, auto buf_c) {
     constexpr int buf = decltype(buf_c)::value;                 // t / weight buffer of panel kp; panel kp + 1 uses the other ones
-    if (kp + 1 < NKP) dma_w(kp + 1, buf ^ 1);
     if (kp + 2 < NKP) load_x(kp + 2);
     // (one copy of the 1x1 half — 144 accumulator registers pass through it — and the depthwise half before OR after it)
     const bool dw_first = wave >= 4;
     if (dw_first && kp + 1 < NKP) dw_panel(kp + 1, buf ^ 1);
-    mfma_panel(buf);
+    mfma_panel(buf, !dw_first && kp + 1 < NKP ? kp + 1 : -1);
     if (!dw_first && kp + 1 < NKP) dw_panel(kp + 1, buf ^ 1);
     if (kp + 2 < NKP) store_x(buf);                             // halo + taps of panel kp + 2 -> X buffer buf (panel kp's: read a phase ago)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the next panel's weights have landed
