@@ -57,6 +57,39 @@ def test_argument_validation_needs_no_gpu():
     assert rc < 0 and b"multiples of 8" in lib.roma_last_error()
 
 
+def test_refiner_wide_host_packers_lay_out_what_the_header_says():
+    """roma_refiner_wide_taps / roma_refiner_wide_pack are HOST functions (no device): their outputs against the layouts written in
+    include/roma_hip.h, restated here with numpy."""
+    import numpy as np
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    D = 64
+    w25 = rng.integers(1, 60000, size=(25, D)).astype(np.uint16)                 # opaque 16-bit patterns: the packers only move them
+    out = np.zeros(60 * D, dtype=np.uint16)
+    assert lib.roma_refiner_wide_taps(w25.ctypes.data, out.ctypes.data, D) == 0
+    got = out.reshape(D // 32, 5, 4, 2, 6, 4, 2)
+    lo, hi = (0, 2, 4, None, 1, 3), (1, 3, None, 0, 2, 4)                        # tap column of (low half, high half) per pair set
+    for kp in range(D // 32):
+        for dy in range(5):
+            for kq in range(4):
+                for h in range(2):
+                    c0 = kp * 32 + kq * 8 + h * 4
+                    for st in range(6):
+                        want_lo = np.zeros(4, np.uint16) if lo[st] is None else w25[dy * 5 + lo[st], c0:c0 + 4]
+                        want_hi = np.zeros(4, np.uint16) if hi[st] is None else w25[dy * 5 + hi[st], c0:c0 + 4]
+                        assert (got[kp, dy, kq, h, st, :, 0] == want_lo).all() and (got[kp, dy, kq, h, st, :, 1] == want_hi).all()
+    assert lib.roma_refiner_wide_taps(w25.ctypes.data, out.ctypes.data, 48) < 0 and b"multiple of 32" in lib.roma_last_error()
+    wt = rng.integers(0, 60000, size=(D, D)).astype(np.uint16)
+    wp = np.zeros(D * D, dtype=np.uint16)
+    assert lib.roma_refiner_wide_pack(wt.ctypes.data, wp.ctypes.data, D) == 0
+    gotp = wp.reshape(D // 32, D, 4, 8)
+    for kp in range(D // 32):
+        for n in range(D):
+            for slot in range(4):
+                kgl = slot ^ ((n >> 1) & 3)
+                assert (gotp[kp, n, slot] == wt[n, kp * 32 + kgl * 8: kp * 32 + kgl * 8 + 8]).all()
+
+
 def test_ops_refuse_cpu_tensors():
     import pytest
     import torch
