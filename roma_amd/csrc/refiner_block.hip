@@ -12,7 +12,9 @@
 //   * the BN+ReLU result, packed to fp16/bf16, IS the A fragment of v_mfma_f32_16x16x32 (lane (m, kq) holds channels
 //     32 ks + 8 kq .. +8 of pixel m), so the 1x1 conv runs on the matrix cores straight out of registers;
 //   * results go through LDS for 16-byte coalesced stores.
+#include <cstdlib>
 #include "common.h"
+#include "lc_device.h"
 
 namespace roma {
 namespace {
@@ -217,10 +219,249 @@ int launch_rb(RBParams p, hipStream_t s) {
   ROMA_CHECK_LAUNCH();
 }
 
+template <typename T> int launch_rb_toep(RBParams p, hipStream_t s);   // the D = 24 block with the depthwise on the matrix cores (below)
+
 template <typename T>
 int launch_rb_any(const RBParams& p, int kpad, hipStream_t s) {
+  if (kpad == 32 && p.C == 24) {
+    static int toep = -1;                                          // ROMA_RB_TOEP=0: the VALU depthwise (A/B aid)
+    if (toep < 0) { const char* e = getenv("ROMA_RB_TOEP"); toep = e ? atoi(e) : 1; }
+    if (toep) return launch_rb_toep<T>(p, s);
+  }
   if (kpad == 32) return p.C == 24 ? launch_rb<T, 1, 3>(p, s) : launch_rb<T, 1, 0>(p, s);
   return launch_rb<T, 5, 0>(p, s);
+}
+
+
+// ---- The D = 24 block with the DEPTHWISE ON THE MATRIX CORES (late round 3) -------------------------------------------------------
+// refiner_block_kernel<T, 1> is bound by its 400 v_fma_mix per tile-lane: the multiply-add forms a 16-bit depthwise can use all issue
+// at ~4.2 cycles per SIMD (profiles/r03_valu_rates.txt), 38-76 TMAC/s chip-wide.  A 5-tap row filter is a banded Toeplitz product,
+//   out[c][row][x] = sum_dy sum_x' T_{c,dy}[x][x'] in[c][row + dy][x'],   T_{c,dy}[x][x'] = w[c][dy][x' - x] for 0 <= x' - x <= 4,
+// i.e. ONE v_mfma_f32_16x16x32 per (channel, tap row) for a 16 x 16-pixel tile: M = output column x, N = tile row, K = halo column x'
+// (20 used of 32).  16 % of its multiply-adds are useful — and that is still ~2.6x the dot2 rate and ~5x v_fma_mix.  The price is
+// layout: K is the pixel column, so the input halo lives in LDS as channel PLANES [c][20 rows][32 columns] (16-bit scatter writes from
+// the channels-last packets) and the BN + ReLU result goes back to channels-last [pixel][32 channels] for the 1x1 (whole 16-byte
+// packets: a wave owns the 8 channels of one packet).  The 120 Toeplitz fragments (24 channels x 5 tap rows, 768 bytes each: lane
+// quarters 0-2; quarter 3 = columns 24-31 is all zero and never read) are built once per persistent workgroup and stay in LDS.
+// Tile = 16 x 16 pixels, 256 threads; per tile: waves 0-2 do the depthwise of packet 0-2 (40 MFMAs each) while the next tile's halo is
+// in flight in registers; then every wave 8 MFMAs of the 1x1; accumulators -> LDS -> 16-byte stores; halo scatter of the next tile.
+constexpr int TPX = 16, TPY = 16, TPHX = TPX + 4, TPHY = TPY + 4;
+constexpr int TP_PR = 64;                                        // bytes per plane row: 32 columns (20 used; the rest stays zero)
+constexpr int TP_PLB = TPHY * TP_PR;                             // bytes per channel plane
+constexpr int TP_NCH = 24, TP_FRAG = 13 * 16;                    // channels; bytes per Toeplitz fragment: 12 distinct 16-byte windows + a zero one
+constexpr int TP_TROW = TPX * 64 + 16;                           // bytes per tile row of t (+16: rows start 4 banks apart: conflict-free packet writes)
+constexpr int TP_OS = 40;                                        // out staging: 16-bit elements per pixel (80 bytes)
+constexpr int TP_TOEP = TP_NCH * 5 * TP_FRAG;
+constexpr int TP_PL = TP_NCH * TP_PLB, TP_TB = TPX * TPY * TP_OS * 2, TP_PW = 32 * 5 * 16;
+constexpr int TP_SMEM = TP_TOEP + TP_PL + TP_TB + TP_PW + 3 * 32 * 4;
+static_assert(TPY * TP_TROW <= TP_TB && 2 * TP_SMEM <= 160 * 1024, "LDS budget of the Toeplitz block: two workgroups per CU");
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void refiner_block_toep_kernel(RBParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* s_toep = smem;                                  // [24 c][5 dy][13 windows][16 B]
+  unsigned char* s_pl = s_toep + TP_TOEP;                        // [24 c][20 rows][64 B]
+  unsigned char* s_t = s_pl + TP_PL;                             // t: [16 rows][TP_TROW]; then out staging [256 pixels][80 B]
+  u32x4* s_pw = reinterpret_cast<u32x4*>(s_t + TP_TB);           // [32 out channels][5 packets] (4 used)
+  float* s_cs = reinterpret_cast<float*>(s_pw + 32 * 5);         // scale[32], shift[32], bias[32]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15, q = lane >> 4;
+  const T* x = static_cast<const T*>(p.x);
+  T* y = static_cast<T*>(p.y);
+  const int tiles_per_img = p.tiles_x * p.tiles_y;
+  auto tile_origin = [&](int tile, int& b, int& ty0, int& tx0) {
+    b = (int)(((float)tile + 0.5f) * p.inv_tiles_per_img);
+    const int tt = tile - b * tiles_per_img;
+    const int tyi = (int)(((float)tt + 0.5f) * p.inv_tiles_x);
+    ty0 = tyi * TPY;
+    tx0 = (tt - tyi * p.tiles_x) * TPX;
+  };
+
+  // ---- once per workgroup ----
+  {
+    const T* w25 = static_cast<const T*>(p.w25);                 // (25, 32)
+    // Toeplitz fragments.  Lane (mm, qq) of fragment (c, dy) holds T[mm][8 qq + j] = w[c][dy][s + j], s = 8 qq - mm, zero outside taps
+    // 0..4: a 16-byte WINDOW of the zero-padded tap row that depends on s alone, and only s = -7 .. 4 gives a non-zero one.  So a
+    // fragment is stored as those 12 windows + a zero window (208 bytes instead of 1 KB: the whole table 25 KB instead of 92 KB, which
+    // is what lets two workgroups share a CU) and a lane reads window min(s + 7, 12) — equal addresses broadcast, the 13 distinct ones
+    // sit in different banks.
+    for (int i = tid; i < TP_NCH * 5 * 13; i += 256) {
+      const int f = i / 13, wi = i - f * 13, c = f / 5, dy = f - c * 5;
+      T v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int dx = wi - 7 + j;
+        v[j] = (wi < 12 && dx >= 0 && dx <= 4) ? w25[(dy * 5 + dx) * 32 + c] : from_f32<T>(0.f);
+      }
+      *reinterpret_cast<u32x4*>(s_toep + (size_t)i * 16) = *reinterpret_cast<const u32x4*>(v);
+    }
+    for (int i = tid; i < 32 * 4; i += 256) s_pw[(i >> 2) * 5 + (i & 3)] = reinterpret_cast<const u32x4*>(p.wt)[i];
+    if (tid < 32) { s_cs[tid] = p.scale[tid]; s_cs[32 + tid] = p.shift[tid]; s_cs[64 + tid] = p.bias[tid]; }
+    for (int i = tid; i < (TP_PL + TP_TB) / 16; i += 256) reinterpret_cast<u32x4*>(s_pl)[i] = u32x4{0, 0, 0, 0};   // plane padding, t's fourth packet
+  }
+  const int ntile = tiles_per_img * p.B;
+  // halo of a tile: 400 positions x 3 packets, item idx = k * 400 + position (a wave-instruction = 64 consecutive positions of one packet)
+  constexpr int NLD = (TPHX * TPHY * 3 + 255) / 256;
+  u32x4 pre[NLD];
+  uint32_t okm = 0;                                              // bit j: item j of the fetched tile lies inside the image
+  uint32_t pdst[NLD];                                            // plane byte offset of element 0 of the item (0xffffffff: no item)
+  int ihy[NLD], ihx[NLD], ik8[NLD];                              // the item's halo row / column / first channel (tile-independent)
+#pragma unroll
+  for (int j = 0; j < NLD; ++j) {
+    const int idx = tid + 256 * j, idc = min(idx, TPHX * TPHY * 3 - 1);
+    const int k = idc / (TPHX * TPHY), pos = idc - k * (TPHX * TPHY), hy = pos / TPHX, hx = pos - hy * TPHX;
+    pdst[j] = idx < TPHX * TPHY * 3 ? (uint32_t)(k * 8 * TP_PLB + hy * TP_PR + hx * 2) : 0xffffffffu;
+    ihy[j] = hy - 2; ihx[j] = hx - 2; ik8[j] = k * 8;
+  }
+  auto fetch = [&](int tile) {
+    int b, ty0, tx0;
+    tile_origin(tile, b, ty0, tx0);
+    const T* xb = x + (size_t)b * p.H * p.W * p.x_pitch;
+    okm = 0xffffffffu;                                           // (the zero padding is applied by scatter(): a select right behind a load waits for it)
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int yy = ty0 + ihy[j], xx = tx0 + ihx[j];
+      if (!(yy >= 0 && yy < p.H && xx >= 0 && xx < p.W)) okm &= ~(1u << j);
+      pre[j] = *reinterpret_cast<const u32x4*>(xb + (uint32_t)((min(max(yy, 0), p.H - 1) * p.W + min(max(xx, 0), p.W - 1)) * p.x_pitch + ik8[j]));
+    }
+  };
+  auto scatter = [&]() {                                         // registers -> channel planes, one 16-bit write per element
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      if (pdst[j] == 0xffffffffu) continue;
+      const bool ok = (okm >> j) & 1u;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const uint32_t w = ok ? pre[j][e >> 1] : 0u;
+        *reinterpret_cast<uint16_t*>(s_pl + pdst[j] + e * TP_PLB) = (uint16_t)((e & 1) ? (w >> 16) : (w & 0xffffu));
+      }
+    }
+  };
+  if ((int)blockIdx.x < ntile) fetch(blockIdx.x);
+  __syncthreads();                                               // tables and zero fill done
+  if ((int)blockIdx.x < ntile) scatter();
+  if ((int)(blockIdx.x + gridDim.x) < ntile) fetch(blockIdx.x + gridDim.x);   // `pre` always holds the tile after the one in the planes
+  __syncthreads();
+
+  const int swz = (m >> 1) & 3;                                  // packet swizzle of t rows (pixel column m), as in refiner_wide.hip
+  const int wsh = 8 * q - m;                                     // this lane's Toeplitz window: start tap s = 8 q - m, non-zero for -7 <= s <= 4
+  const int woff = (wsh >= -7 && wsh <= 4 ? wsh + 7 : 12) * 16;
+  // BN constants of this wave's channel packet and the bias of this lane's output channels: in registers for the whole kernel (read
+  // from LDS per channel, every read also waited for the ten operand reads issued ahead of it: 3 100 cycles of depthwise per tile)
+  float scv[8], shv[8], bsv4[2][4];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { scv[e] = s_cs[min(wv, 2) * 8 + e]; shv[e] = s_cs[32 + min(wv, 2) * 8 + e]; }
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bsv4[nb][i] = s_cs[64 + nb * 16 + 4 * q + i];
+  for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    int b, ty0, tx0;
+    tile_origin(tile, b, ty0, tx0);
+    const bool more = tile + (int)gridDim.x < ntile, more2 = tile + 2 * (int)gridDim.x < ntile;
+    // ---- depthwise + BN + ReLU: wave k < 3 owns channel packet k; lane (m = tile row for B / output column for A, q) ----
+    if (wv < 3) {
+      float vals[8][4];
+      // the ten operand reads of channel e + 1 are issued before the five MFMAs of channel e (left to itself hipcc put every pair of
+      // reads and an lgkmcnt(0) directly in front of its MFMA: 40 exposed LDS round trips per tile, 103 us at 864^2)
+      // hipcc put every pair of operand reads and an lgkmcnt(0) directly in front of its MFMA (40 exposed LDS round trips per tile);
+      // with all ten reads of the next channel issued ahead, the 4-bit lgkmcnt still made every channel wait for reads just issued.
+      // So: the two reads for tap row dy of channel e + 1 go out right behind the MFMA of tap row dy of channel e (eight reads younger
+      // than the one an MFMA waits for).
+      u32x4 av[5], bv[5];
+      auto load_op = [&](int c, int dy, u32x4& a, u32x4& bq) {
+        a = *reinterpret_cast<const u32x4*>(s_toep + (c * 5 + dy) * TP_FRAG + woff);
+        bq = *reinterpret_cast<const u32x4*>(s_pl + c * TP_PLB + (m + dy) * TP_PR + q * 16);
+      };
+#pragma unroll
+      for (int dy = 0; dy < 5; ++dy) load_op(wv * 8, dy, av[dy], bv[dy]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = wv * 8 + e;
+        u32x4 an[5], bn[5];
+        float4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dy = 0; dy < 5; ++dy) {
+          __builtin_amdgcn_sched_barrier(0);
+          acc = lc::mfma16r(av[dy], bv[dy], acc, T{});
+          if (e < 7) load_op(c + 1, dy, an[dy], bn[dy]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vals[e][i] = fmaxf(__builtin_fmaf(acc[i], scv[e], shv[e]), 0.f);
+        if (e < 7) {
+#pragma unroll
+          for (int dy = 0; dy < 5; ++dy) { av[dy] = an[dy]; bv[dy] = bn[dy]; }
+        }
+      }
+      // lane (q, m) holds output columns 4 q + i of tile row m, 8 channels: one 16-byte packet per pixel
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float f8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f8[e] = vals[e][i];
+        const int xo = 4 * q + i;
+        *reinterpret_cast<u32x4*>(s_t + m * TP_TROW + xo * 64 + ((wv ^ ((xo >> 1) & 3)) << 4)) = pack16<T>(f8);
+      }
+    }
+    __syncthreads();
+    // ---- 1x1 on the matrix cores: wave w takes tile rows 4 w .. 4 w + 3, both 16-channel output blocks.  Operands swapped (A = weight
+    // rows, B = t rows) so that lane (q, m) ends up with output channels 16 nb + 4 q .. + 3 of pixel column m: 8-byte staging writes ----
+    float4_t acc2[4][2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const u32x4 tb = *reinterpret_cast<const u32x4*>(s_t + (wv * 4 + r) * TP_TROW + m * 64 + ((q ^ swz) << 4));
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) acc2[r][nb] = lc::mfma16r(s_pw[(nb * 16 + m) * 5 + q], tb, float4_t{0.f, 0.f, 0.f, 0.f}, T{});
+    }
+    __syncthreads();                                             // every wave is done reading t
+    T* s_out = reinterpret_cast<T*>(s_t);                        // [256 pixels][TP_OS]
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        T o4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o4[i] = from_f32<T>(acc2[r][nb][i] + bsv4[nb][i]);
+        *reinterpret_cast<uint2*>(s_out + ((wv * 4 + r) * TPX + m) * TP_OS + nb * 16 + 4 * q) = *reinterpret_cast<const uint2*>(o4);
+      }
+    // The halo pipeline is two tiles deep: the registers hold tile N + 1 (requested a whole iteration ago), they go to the planes (free
+    // since the first barrier of this tile), and tile N + 2 is requested IN FRONT OF this tile's global stores: requested behind them
+    // (at the top of the loop) the loads sat behind an s_waitcnt vmcnt(0) for the stores — register reuse — 2 400 cycles per tile.
+    if (more) scatter();
+    if (more2) fetch(tile + 2 * gridDim.x);
+    __syncthreads();
+    T* yb = y + (size_t)b * p.H * p.W * p.y_pitch;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int i = tid + 256 * j, pix = i / 3, k = i - pix * 3;
+      const int yy = ty0 + (pix >> 4), xx = tx0 + (pix & 15);
+      if (yy < p.H && xx < p.W)
+        *reinterpret_cast<u32x4*>(yb + ((size_t)yy * p.W + xx) * p.y_pitch + k * 8) = *reinterpret_cast<const u32x4*>(s_out + pix * TP_OS + k * 8);
+    }
+    __syncthreads();                                             // staging read; t's fourth packet must be zero again before the next depthwise
+    for (int i = tid; i < TPX * TPY; i += 256) {
+      const int row = i >> 4, xo = i & 15;
+      *reinterpret_cast<u32x4*>(s_t + row * TP_TROW + xo * 64 + ((3 ^ ((xo >> 1) & 3)) << 4)) = u32x4{0, 0, 0, 0};
+    }
+    // (no barrier needed here: the depthwise writes other slots of t, and the next reader of the zero slots is behind the next barrier)
+  }
+}
+
+template <typename T>
+int launch_rb_toep(RBParams p, hipStream_t s) {
+  static std::atomic<uint64_t> attr_done{0};
+  if (int rc = ensure_dyn_smem(reinterpret_cast<const void*>(refiner_block_toep_kernel<T>), TP_SMEM, attr_done, "roma_refiner_block")) return rc;
+  p.tiles_x = (p.W + TPX - 1) / TPX;
+  p.tiles_y = (p.H + TPY - 1) / TPY;
+  const long ntile = (long)p.B * p.tiles_x * p.tiles_y;
+  ROMA_REQUIRE(ntile < (1 << 21), ROMA_E_SHAPE, "roma_refiner_block: %ld tiles in one launch (< 2^21)", ntile);
+  p.inv_tiles_per_img = 1.0f / (float)(p.tiles_x * p.tiles_y);
+  p.inv_tiles_x = 1.0f / (float)p.tiles_x;
+  const int grid = ntile < 2 * num_cus() ? (int)ntile : 2 * num_cus();      // persistent, two workgroups per CU
+  hipLaunchKernelGGL((refiner_block_toep_kernel<T>), dim3(grid), dim3(256), TP_SMEM, s, p);
+  ROMA_CHECK_LAUNCH();
 }
 
 

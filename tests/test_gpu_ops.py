@@ -793,9 +793,12 @@ def test_tiny_corr_posembed_full_size():
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("C,kpad,B,H,W", [(144, 160, 1, 37, 45), (24, 32, 2, 19, 50), (144, 160, 2, 8, 16), (32, 32, 1, 64, 64), (160, 160, 1, 23, 17)])
+@pytest.mark.parametrize("C,kpad,B,H,W", [(144, 160, 1, 37, 45), (24, 32, 2, 19, 50), (144, 160, 2, 8, 16), (32, 32, 1, 64, 64), (160, 160, 1, 23, 17),
+                                         (24, 32, 1, 16, 16), (24, 32, 3, 33, 17), (24, 32, 1, 400, 376), (24, 32, 1, 5, 3)])
 def test_refiner_block_vs_torch(dtype, C, kpad, B, H, W):
-    """Fused ConvRefiner block vs conv2d(groups)+BN+ReLU+1x1 in fp32 on the same (rounded) operands — matcher.py:77-103."""
+    """Fused ConvRefiner block vs conv2d(groups)+BN+ReLU+1x1 in fp32 on the same (rounded) operands — matcher.py:77-103.
+    C = 24 runs the kernel with the depthwise on the matrix cores (16 x 16-pixel tiles, persistent workgroups: 400 x 376 is 600 tiles for
+    512 workgroups, so the two-tile-deep halo pipeline wraps; 5 x 3 is one partial tile)."""
     import torch.nn.functional as F
     ops, dev = _ops(), DEV
     g = torch.Generator().manual_seed(C * 1000 + H)
