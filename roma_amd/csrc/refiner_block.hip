@@ -12,6 +12,7 @@
 //   * the BN+ReLU result, packed to fp16/bf16, IS the A fragment of v_mfma_f32_16x16x32 (lane (m, kq) holds channels
 //     32 ks + 8 kq .. +8 of pixel m), so the 1x1 conv runs on the matrix cores straight out of registers;
 //   * results go through LDS for 16-byte coalesced stores.
+#include <algorithm>
 #include <cstdlib>
 #include "common.h"
 #include "lc_device.h"
@@ -464,6 +465,11 @@ int launch_rb_toep(RBParams p, hipStream_t s) {
   ROMA_CHECK_LAUNCH();
 }
 
+
+// (The same depthwise as a STAND-ALONE kernel for the wide levels — one workgroup per group of 24 channels, output packets straight to
+// global — was built and measured late in round 3 and removed again: 1.5-1.8 TB/s at D = 144 .. 1384 against the 2.3-3.2 TB/s of
+// dwconv.hip's VALU kernel; the 48-byte pieces per pixel, the halo re-read per group and the 16-bit plane scatter cost more than the
+// matrix cores save.  It wins only where a whole pixel is one group, i.e. here.  Numbers in DESIGN.md §3.3.)
 
 // ---- 1x1 convolution alone at mid widths (32 < C <= 160), for the refiner whose depthwise half stays a separate kernel:
 // y[m][n] = bias[n] + sum_k x[m][k] * wt[n][k].  hipBLASLt runs this skinny GEMM (N = K = 144, M = 10^5..10^6) at ~2 TB/s of
