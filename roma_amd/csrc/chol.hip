@@ -18,7 +18,7 @@
 //   inverse:      (4) the four 16 x 16 diagonal blocks of L^-1 by forward substitution (one thread per column), then the
 //                     off-diagonal blocks as small products, W21 = -W22 (L21 W11), first inside each 32 x 32 half, then the
 //                     32 x 32 block below the diagonal.
-// Round 3 (tools/scratch/chol_prof: wall-clock stamps inside the diagonal workgroup of a blocked step): of 44 us per step, 10 us were
+// Round 3 (tools/prof/chol_prof: wall-clock stamps inside the diagonal workgroup of a blocked step): of 44 us per step, 10 us were
 // 32 SERIALISED global loads (hipcc had put a vmcnt(0) into every iteration of the tile-load loops), 13 us the four diagonal blocks
 // (IEEE sqrt + IEEE division per pivot), 6 us the trailing updates; with the loads batched, rcp / rsq pivots and register-tiled updates a
 // step's workgroup takes 31 us, the 25-step chain 0.96 ms instead of 1.25 ms, ops.spd_solve 1.17 ms instead of 1.49 ms.

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(512, 1) void refiner_wide_kernel(RWParams p) {
   // the weight panel: WBUF / 1024 = 36 wave-instructions (1 KB each).  Prologue: all eight waves share them.  Inside a phase they are
   // issued by waves 0-3 ONE AT A TIME between the nine MFMA blocks of their 1x1 half (mfma_panel): issued together at the start of
   // the phase, 36 KB of DMA + the halo loads kept the vector-memory issue of all eight waves blocked for ~900 of the phase's 5800
-  // cycles (tools/scratch/rw_prof: two plain loads took a depthwise-first wave 1000 cycles to issue), and those waves — whose LDS
+  // cycles (tools/prof/rw_prof: two plain loads took a depthwise-first wave 1000 cycles to issue), and those waves — whose LDS
   // reads then ran against the landing weights — were the critical path while waves 0-3 idled ~1100 cycles at the barrier.
   auto dma_w_all = [&](int kp, int buf) {
     const unsigned char* src = static_cast<const unsigned char*>(p.wp) + (size_t)kp * WBUF;
