@@ -23,11 +23,13 @@
 #ifndef ROMA_HIP_H
 #define ROMA_HIP_H
 
+#include <stdint.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define ROMA_ABI_VERSION 4
+#define ROMA_ABI_VERSION 5
 
 enum { ROMA_F32 = 0, ROMA_F16 = 1, ROMA_BF16 = 2 };
 enum { ROMA_NCHW = 0, ROMA_NHWC = 1 };
@@ -264,6 +266,21 @@ int roma_add_layernorm(void* x, int x_dtype, long x_stride, const void* y, int y
  *   exact != 0: full softmax expectation (tiny.py:201-202); exact == 0: reference fast path (tiny.py:187-198). */
 int roma_tiny_corr_posembed(const float* f0, const float* f1, float* out, int B, int C,
                             int H0, int W0, int H1, int W1, int exact, void* stream);
+
+/* Baseline JPEG decoding for match() on file paths — romatch/models/matcher.py:606-637, 667-676 (`Image.open(path).convert("RGB")`:
+ * PIL -> libjpeg-turbo with its defaults, JDCT_ISLOW + fancy up-sampling).  The entropy-coded segment is decoded on the HOST
+ * (roma_jpeg_info, roma_jpeg_entropy_decode: host functions, all pointers in host memory); de-quantisation + inverse DCT, chroma
+ * up-sampling and YCbCr -> RGB run on the device (roma_jpeg_reconstruct) and leave a uint8 (height, width, 3) image for
+ * roma_resample_u8 / roma_normalize_u8.  Bit-identical to PIL.  Supported: 8-bit baseline sequential Huffman, 1 or 3 components,
+ * 4:4:4 or 4:2:0, one interleaved scan, restart intervals; anything else returns ROMA_E_UNSUPPORTED (decode with PIL on the host then).
+ *   info[8]: width, height, components, sub-sampling (0: 4:4:4, 1: 4:2:0, -1: grey), luma blocks per row, luma block rows, chroma
+ *            blocks per row, chroma block rows;
+ *   coef: int16, (luma + 2 x chroma blocks) x 64, natural order inside a block, blocks of a component in raster order, components
+ *         one after the other; qt: 3 x 64 uint16, the component's de-quantisation table in natural order;
+ *   planes: device scratch, (luma + 2 x chroma blocks) x 64 bytes; rgb: device, height x width x 3 bytes. */
+int roma_jpeg_info(const void* data, long nbytes, int* info);
+int roma_jpeg_entropy_decode(const void* data, long nbytes, int16_t* coef, uint16_t* qt);
+int roma_jpeg_reconstruct(const int16_t* coef, const uint16_t* qt, void* planes, void* rgb, const int* info, void* stream);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,8 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libroma_hip.so")
 ROMA_F32, ROMA_F16, ROMA_BF16 = 0, 1, 2
 ROMA_NCHW, ROMA_NHWC = 0, 1
 LC_VARIANTS = {"auto": 0, "tile8x4": 1, "tile8x8": 2, "rows8": 3}
-ABI_VERSION = 4
+ABI_VERSION = 5
+ROMA_E_ARG, ROMA_E_DTYPE, ROMA_E_SHAPE, ROMA_E_ALIGN, ROMA_E_UNSUPPORTED = -1, -2, -3, -4, -5      # include/roma_hip.h
 
 # name -> argtypes; restype is c_int unless listed in _RESTYPES.  Mirrors include/roma_hip.h one to one.
 SIGNATURES = {
@@ -51,6 +52,9 @@ SIGNATURES = {
                            c_int, c_int, c_void_p],
     "roma_refiner_wide_pack": [c_void_p, c_void_p, c_int],
     "roma_refiner_wide_taps": [c_void_p, c_void_p, c_int],
+    "roma_jpeg_info": [c_void_p, c_long, c_void_p],
+    "roma_jpeg_entropy_decode": [c_void_p, c_long, c_void_p, c_void_p],
+    "roma_jpeg_reconstruct": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "roma_refiner_block_wide": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                 c_int, c_void_p],
     "roma_refiner_head": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,

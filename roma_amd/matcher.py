@@ -494,6 +494,7 @@ class RegressionMatcher(nn.Module):
         self.symmetric = symmetric
         self.sample_thresh = 0.05
         self.host_preprocess = False          # True: PIL resize on the host like the reference (same bits, slower)
+        self.device_jpeg = True               # baseline JPEG paths: entropy decoding on the host, IDCT / up-sampling / RGB on the device (same bits as PIL)
 
     def get_output_resolution(self):
         return self.upsample_res if self.upsample_preds else (self.h_resized, self.w_resized)
@@ -718,6 +719,14 @@ class RegressionMatcher(nn.Module):
         ims = []
         for im in (im_A_input, im_B_input):
             if isinstance(im, (str, os.PathLike)):
+                if not getattr(self, "host_preprocess", False) and getattr(self, "device_jpeg", True):
+                    # baseline JPEG files: Huffman decoding on the host, everything after it on the device, bit-identical to PIL
+                    # (preproc.decode_jpeg_device; None = a stream the kernels do not cover -> PIL below)
+                    from .preproc import decode_jpeg_device
+                    dec = decode_jpeg_device(im, device) if str(im).lower().endswith((".jpg", ".jpeg")) else None
+                    if dec is not None:
+                        ims.append(dec)
+                        continue
                 im = Image.open(im)
                 _check_not_i16(im)
                 im = im.convert("RGB")
@@ -731,7 +740,7 @@ class RegressionMatcher(nn.Module):
         else:
             # one uint8 upload per photograph; both resolutions are resized + normalised on the device, bit-identical to PIL
             from .preproc import preprocess_device
-            src = [torch.from_numpy(np.array(im, dtype=np.uint8)).to(device) for im in ims]
+            src = [im if isinstance(im, torch.Tensor) else torch.from_numpy(np.array(im, dtype=np.uint8)).to(device) for im in ims]
             lo = [preprocess_device(s, (self.h_resized, self.w_resized), device)[None] for s in src]
             hi = [preprocess_device(s, self.upsample_res, device)[None] for s in src] if self.upsample_preds else [None, None]
         warp, cert = self.match_tensors(lo[0], lo[1], hi[0], hi[1])

@@ -118,3 +118,53 @@ def preprocess_device(im, size, device) -> torch.Tensor:
     else:
         src = torch.from_numpy(np.array(im, dtype=np.uint8)).to(device)
     return ops.normalize_u8(resize_device(src, size), IMAGENET_MEAN, IMAGENET_STD)
+
+
+_JPEG_STAGING = {"buf": None, "event": None}
+
+
+def decode_jpeg_device(data, device):
+    """JPEG bytes (or a path) -> uint8 (H, W, 3) RGB tensor on `device`, bit-identical to `np.array(Image.open(..).convert("RGB"))`
+    (matcher.py:606-637, 667-676).  The Huffman decoding runs on the host (roma_jpeg_entropy_decode), de-quantisation + inverse DCT +
+    chroma up-sampling + colour conversion on the GPU (roma_jpeg_reconstruct): only the quantised coefficients cross PCIe.
+    Returns None for streams the kernels do not cover (progressive, 4:2:2, CMYK, 12-bit, arithmetic coding): decode those with PIL."""
+    import os
+    from . import _lib
+    from ._lib import check
+    if isinstance(data, (str, os.PathLike)):
+        with open(data, "rb") as fh:
+            data = fh.read()
+    lib = _lib.load()
+    buf = np.frombuffer(data, dtype=np.uint8)
+    info = np.zeros(8, dtype=np.int32)
+    rc = lib.roma_jpeg_info(buf.ctypes.data, len(data), info.ctypes.data)
+    if rc == _lib.ROMA_E_UNSUPPORTED or rc == _lib.ROMA_E_ARG:
+        return None
+    check(rc, "roma_jpeg_info")
+    W, H = int(info[0]), int(info[1])
+    nblocks = int(info[4]) * int(info[5]) + 2 * int(info[6]) * int(info[7])
+    device = torch.device(device)
+    # one grow-only pinned staging buffer per process (pinning 9 MB per call costs more than decoding it); the previous image's
+    # upload must have left it before the host writes the next one
+    need = (nblocks + 3) * 64
+    st = _JPEG_STAGING
+    if st["event"] is not None:
+        st["event"].synchronize()
+    if st["buf"] is None or st["buf"].numel() < need:
+        st["buf"] = torch.empty((max(need, 1 << 20),), dtype=torch.int16).pin_memory()
+    coef = st["buf"][:nblocks * 64].view(nblocks, 64)
+    qt = st["buf"][nblocks * 64:(nblocks + 3) * 64].view(3, 64)       # uint16 bit patterns
+    rc = lib.roma_jpeg_entropy_decode(buf.ctypes.data, len(data), coef.data_ptr(), qt.data_ptr())
+    if rc == _lib.ROMA_E_ARG:                                        # a corrupt stream: let PIL produce its own error / partial image
+        return None
+    check(rc, "roma_jpeg_entropy_decode")
+    both = st["buf"][:need].to(device, non_blocking=True)
+    st["event"] = torch.cuda.Event()
+    st["event"].record(torch.cuda.current_stream(device))
+    coef_d, qt_d = both[:nblocks * 64], both[nblocks * 64:]
+    planes = torch.empty((nblocks * 64,), dtype=torch.uint8, device=device)
+    rgb = torch.empty((H, W, 3), dtype=torch.uint8, device=device)
+    with torch.cuda.device(device):
+        check(lib.roma_jpeg_reconstruct(coef_d.data_ptr(), qt_d.data_ptr(), planes.data_ptr(), rgb.data_ptr(), info.ctypes.data,
+                                        torch.cuda.current_stream().cuda_stream), "roma_jpeg_reconstruct")
+    return rgb

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_version_and_error_string():
     lib = _lib.load()
-    assert lib.roma_abi_version() == 4
+    assert lib.roma_abi_version() == 5
     assert isinstance(lib.roma_last_error(), bytes)
 
 

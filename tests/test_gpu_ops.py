@@ -42,7 +42,7 @@ def solve64(K, F):
 
 def test_library_is_loaded_and_on_gpu():
     from roma_amd import _lib
-    assert _lib.load().roma_abi_version() == 4
+    assert _lib.load().roma_abi_version() == 5
     assert torch.cuda.is_available()
     with pytest.raises(RuntimeError):
         _ops().local_correlation(torch.zeros(1, 8, 4, 4), torch.zeros(1, 8, 4, 4), 2)     # CPU tensors: loud failure
