@@ -258,6 +258,31 @@ def test_warp_bilinear(dtype, C, layout):
     assert maxerr(out, ref) <= (1e-5 if dtype == torch.float32 else 4e-3)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("C,pitch,off", [(9, 24, 9), (9, 24, 10), (3, 8, 3), (12, 32, 14), (16, 40, 17), (5, 16, 8)])
+def test_warp_bilinear_few_channels_inside_a_wider_pixel(dtype, C, pitch, off):
+    """The scale-1 refiner's call: source = channels [0, C) of a channels-last concat buffer, destination = channels [off, off + C)
+    of the SAME buffer (any 2-byte alignment), the source batch-shifted by B / 2 — the one-thread-per-pixel kernel of sampling.hip
+    (C <= 16, not a whole number of packets).  Reference: F.grid_sample on the rounded source; the other channels must stay untouched."""
+    import torch.nn.functional as F
+    B, h, w = 4, 19, 26
+    buf = torch.full((B, h, w, pitch), 7.0, device=DEV, dtype=dtype)
+    d = buf.permute(0, 3, 1, 2)
+    d[:, :C] = H.T(R.normal(f"warps.src.{C}", (B, C, h, w))).to(DEV).to(dtype)
+    src = d[:, :C]
+    flow = H.T(R.adversarial_flow("warps.flow", B, h, w, lim=1.1), DEV)
+    rolled = torch.roll(src.float(), shifts=-(B // 2), dims=0)                                 # y[b] = x[(b + B/2) % B]
+    ref = F.grid_sample(rolled, flow.permute(0, 2, 3, 1), mode="bilinear", align_corners=False)
+    out = _ops().warp_bilinear(src, flow, out=d[:, off:off + C], batch_shift=B // 2)
+    assert out.data_ptr() == buf.data_ptr() + off * buf.element_size()
+    tol = 4e-3 if dtype == torch.float16 else 3e-2
+    assert maxerr(out, ref) <= tol
+    keep = torch.ones(pitch, dtype=torch.bool)
+    keep[:C] = False
+    keep[off:off + C] = False
+    assert bool((buf[..., keep.to(DEV)] == 7.0).all())
+
+
 @pytest.mark.parametrize("sizes", [((40, 40), (70, 70)), ((70, 70), (140, 140)), ((560, 560), (108, 108)), ((5, 6), (30, 36)), ((7, 9), (7, 9))])
 def test_interp_bilinear(sizes):
     import torch.nn.functional as F

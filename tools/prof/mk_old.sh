@@ -3,7 +3,7 @@
 set -e
 cd /root/repo/roma_amd/csrc
 objs=""
-for o in local_corr local_corr_t8 local_corr_rows sampling cls_refine cos_kernel chol finalize kde dwconv pointwise refiner_head refiner_block refiner_wide bias_relu preproc tiny_corr layernorm sample attention error; do
+for o in local_corr local_corr_t8 local_corr_rows sampling cls_refine cos_kernel chol finalize kde dwconv pointwise refiner_head refiner_block refiner_wide bias_relu preproc tiny_corr layernorm sample attention jpeg error; do
   use=$o.o
   for f in "$@"; do
     if [ "$f" = "$o.hip" ]; then
