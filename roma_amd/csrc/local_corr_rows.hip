@@ -126,6 +126,15 @@ __global__ __launch_bounds__(64 * NW) void local_corr_rows_kernel(LCTileParams p
   const int y = gpy + (n16 >> 2), x = gpx + (n16 & 3);
   const bool pvalid = y < H && x < W;
 
+  // ---- the flow of this lane's pixel is requested FIRST: the targets, the boxes and the first stages depend on it, the A operand is
+  // not needed before the first MFMA — the wait below lets the NCB * 8 A loads stay in flight behind it (a one-round launch is a latency
+  // chain; with the A loads in front every tile waited for them before it could even compute its box) ----
+  float fx_raw = 0.f, fy_raw = 0.f;
+  if (pvalid && p.flow) {
+    const float* fb = p.flow + (size_t)b * 2 * H * W;
+    fx_raw = fb[(uint32_t)(y * W + x)];
+    fy_raw = fb[(uint32_t)(H * W + y * W + x)];
+  }
   // ---- A operand: pixel n16 of the group, channels [64 kg, 64 kg + 64) of every 256-channel block, straight into registers ----
   u32x4 a[NCB * 8];
   {
@@ -144,12 +153,13 @@ __global__ __launch_bounds__(64 * NW) void local_corr_rows_kernel(LCTileParams p
   int x0 = 0, y0 = 0;
   float ax = 0.f, ay = 0.f;
   int lox = BIG, loy = BIG, hix = -BIG, hiy = -BIG;
+  // the two flow loads are older than the A loads: wait until only those NCB * 8 are outstanding (vmcnt is in order)
+  __builtin_amdgcn_s_waitcnt(((NCB * 8) & 15) | (((NCB * 8) >> 4) << 14) | 0x0F70);
   if (pvalid) {
     float fx, fy;
     if (p.flow) {
-      const float* fb = p.flow + (size_t)b * 2 * H * W;
-      fx = fb[(uint32_t)(y * W + x)];
-      fy = fb[(uint32_t)(H * W + y * W + x)];
+      fx = fx_raw;
+      fy = fy_raw;
     } else {
       fx = -1.f + (2.f * x + 1.f) / W;
       fy = -1.f + (2.f * y + 1.f) / H;
@@ -160,10 +170,6 @@ __global__ __launch_bounds__(64 * NW) void local_corr_rows_kernel(LCTileParams p
       lox = x0 - R; hix = x0 + R + 1; loy = y0 - R; hiy = y0 + R + 1;
     }
   }
-  // every global load of the prologue has landed; said with the builtin so that hipcc KNOWS its vmcnt scoreboard is empty and puts
-  // no wait of its own into the stage loop (it cannot count the asm LDS-DMAs: a vmcnt(0) it placed in front of an MFMA that reads
-  // `a` drained the ring every stage)
-  __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0), expcnt / lgkmcnt untouched
   if (kg == 0) { s_x0[g * 16 + n16] = x0; s_y0[g * 16 + n16] = y0; s_ax[g * 16 + n16] = ax; s_ay[g * 16 + n16] = ay; }
   lox = row16_min(lox); loy = row16_min(loy); hix = row16_max(hix); hiy = row16_max(hiy);
   const bool gempty = __builtin_amdgcn_readfirstlane((int)(hix < lox));
@@ -291,6 +297,10 @@ __global__ __launch_bounds__(64 * NW) void local_corr_rows_kernel(LCTileParams p
       float4_t acc2 = {0.f, 0.f, 0.f, 0.f};
       if (nstw > 0) issue(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
       if (PFW >= 2 && nstw > 1) issue(std::integral_constant<int, 1 % NSW>{}, std::integral_constant<int, 1 % NCB>{});
+      // every global load of the prologue (the A operand) and the stages just issued have landed; said with the builtin so that hipcc
+      // KNOWS its vmcnt scoreboard is empty and puts no wait of its own into the loop (it cannot count the asm LDS-DMAs: a vmcnt(0) it
+      // placed in front of an MFMA that reads `a` drained the ring every stage)
+      __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0), expcnt / lgkmcnt untouched
       for (int st0 = 0; st0 < nstw; st0 += UNRW) {
 #pragma unroll
         for (int u = 0; u < UNRW; ++u) {
@@ -464,6 +474,10 @@ __global__ __launch_bounds__(64 * NW) void local_corr_rows_kernel(LCTileParams p
     // fill: the first PF stages
     if (PF >= 1 && nst > 0) issue(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
     if (PF >= 2 && nst > 1) issue(std::integral_constant<int, 1 % NS>{}, std::integral_constant<int, 1 % NCB>{});
+    // every global load of the prologue (the A operand) and the stages just issued have landed; said with the builtin so that hipcc
+    // KNOWS its vmcnt scoreboard is empty and puts no wait of its own into the loop (it cannot count the asm LDS-DMAs: a vmcnt(0) it
+    // placed in front of an MFMA that reads `a` drained the ring every stage)
+    __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0), expcnt / lgkmcnt untouched
     for (int st0 = 0; st0 < nst; st0 += UNR) {
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
