@@ -339,10 +339,18 @@ __global__ __launch_bounds__(256, 2) void refiner_block_toep_kernel(RBParams p) 
       }
     }
   };
-  if ((int)blockIdx.x < ntile) fetch(blockIdx.x);
+  // Tile order: the dispatcher deals workgroup b to XCD b % 8, and every XCD has its own L2.  XCD x owns the contiguous eighth `band` of
+  // the tile sequence and its gridDim / 8 workgroups walk that band side by side, so the halo a tile shares with its neighbours (56 % more
+  // input than the tile itself) is in that XCD's L2: FETCH_SIZE was 1.65 x the input with tiles dealt round-robin over all workgroups.
+  const bool xcd_order = (gridDim.x & 7) == 0 && ntile >= 64;
+  const int nx = xcd_order ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+  const int band = xcd_order ? (ntile + 7) >> 3 : ntile;
+  const int t_beg = xcd_order ? (int)(blockIdx.x & 7) * band + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int t_end = xcd_order ? min(((int)(blockIdx.x & 7) + 1) * band, ntile) : ntile;
+  if (t_beg < t_end) fetch(t_beg);
   __syncthreads();                                               // tables and zero fill done
-  if ((int)blockIdx.x < ntile) scatter();
-  if ((int)(blockIdx.x + gridDim.x) < ntile) fetch(blockIdx.x + gridDim.x);   // `pre` always holds the tile after the one in the planes
+  if (t_beg < t_end) scatter();
+  if (t_beg + nx < t_end) fetch(t_beg + nx);                     // `pre` always holds the tile after the one in the planes
   __syncthreads();
 
   const int swz = (m >> 1) & 3;                                  // packet swizzle of t rows (pixel column m), as in refiner_wide.hip
@@ -357,10 +365,10 @@ __global__ __launch_bounds__(256, 2) void refiner_block_toep_kernel(RBParams p) 
   for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
     for (int i = 0; i < 4; ++i) bsv4[nb][i] = s_cs[64 + nb * 16 + 4 * q + i];
-  for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+  for (int tile = t_beg; tile < t_end; tile += nx) {
     int b, ty0, tx0;
     tile_origin(tile, b, ty0, tx0);
-    const bool more = tile + (int)gridDim.x < ntile, more2 = tile + 2 * (int)gridDim.x < ntile;
+    const bool more = tile + nx < t_end, more2 = tile + 2 * nx < t_end;
     // ---- depthwise + BN + ReLU: wave k < 3 owns channel packet k; lane (m = tile row for B / output column for A, q) ----
     if (wv < 3) {
       float vals[8][4];
@@ -431,7 +439,7 @@ __global__ __launch_bounds__(256, 2) void refiner_block_toep_kernel(RBParams p) 
     // since the first barrier of this tile), and tile N + 2 is requested IN FRONT OF this tile's global stores: requested behind them
     // (at the top of the loop) the loads sat behind an s_waitcnt vmcnt(0) for the stores — register reuse — 2 400 cycles per tile.
     if (more) scatter();
-    if (more2) fetch(tile + 2 * gridDim.x);
+    if (more2) fetch(tile + 2 * nx);
     __syncthreads();
     T* yb = y + (size_t)b * p.H * p.W * p.y_pitch;
 #pragma unroll
