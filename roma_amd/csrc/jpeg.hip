@@ -40,6 +40,7 @@ struct Header {
   int restart = 0;
   size_t scan = 0;                                               // offset of the entropy-coded data
   int hmax = 1, vmax = 1;
+  bool adobe_rgb = false, jfif = false;
 };
 
 void build_huff(Huff& h, const uint8_t* counts, const uint8_t* vals, int nvals) {
@@ -117,6 +118,10 @@ int parse(const uint8_t* d, size_t n, Header& H) {
         build_huff(tc ? H.ac[th] : H.dc[th], s + o + 1, s + o + 17, nv);
         o += 17 + nv;
       }
+    } else if (m == 0xEE) {                                      // APP14 "Adobe": transform 0 with three components = stored as RGB, not YCbCr
+      if (sl >= 12 && memcmp(s, "Adobe", 5) == 0 && s[11] == 0) H.adobe_rgb = true;
+    } else if (m == 0xE0) {
+      if (sl >= 5 && memcmp(s, "JFIF", 4) == 0) H.jfif = true;
     } else if (m == 0xDD) {
       if (sl >= 2) H.restart = (s[0] << 8) | s[1];
     } else if (m == 0xDA) {                                      // start of scan: one interleaved scan with all components
@@ -138,6 +143,12 @@ int parse(const uint8_t* d, size_t n, Header& H) {
         }
       }
       H.scan = i + 2 + L;
+      // colour space: YCbCr is what the kernels convert.  libjpeg takes three components for RGB when an Adobe marker says
+      // "transform 0", or — without a JFIF marker — when the component ids spell 'R', 'G', 'B'
+      if (H.ncomp == 3 && (H.adobe_rgb || (!H.jfif && H.comp[0].id == 'R' && H.comp[1].id == 'G' && H.comp[2].id == 'B'))) {
+        set_error("roma_jpeg: three components stored as RGB (no YCbCr transform) are not decoded here");
+        return ROMA_E_UNSUPPORTED;
+      }
       // sampling: grey, 4:4:4 or 4:2:0
       if (H.ncomp == 3) {
         const bool c444 = H.comp[0].h == 1 && H.comp[0].v == 1, c420 = H.comp[0].h == 2 && H.comp[0].v == 2;

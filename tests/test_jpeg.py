@@ -73,6 +73,13 @@ def test_streams_outside_the_baseline_subset_are_refused_not_misdecoded():
         img.save(bio, "JPEG", **kw)
         rc, *_ = _host_decode(bio.getvalue())
         assert rc == _lib.ROMA_E_UNSUPPORTED, kw
+    bio = io.BytesIO()
+    try:
+        img.save(bio, "JPEG", keep_rgb=True)                    # three components stored as RGB (Adobe marker, no YCbCr transform)
+        rc, *_ = _host_decode(bio.getvalue())
+        assert rc == _lib.ROMA_E_UNSUPPORTED
+    except TypeError:                                           # an older Pillow without keep_rgb
+        pass
     rc, *_ = _host_decode(b"\x89PNG\r\n\x1a\n" + b"\0" * 64)
     assert rc == _lib.ROMA_E_ARG
     data = open(ASSETS[0], "rb").read()
