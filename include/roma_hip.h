@@ -272,8 +272,8 @@ int roma_tiny_corr_posembed(const float* f0, const float* f1, float* out, int B,
  * (roma_jpeg_info, roma_jpeg_entropy_decode: host functions, all pointers in host memory); de-quantisation + inverse DCT, chroma
  * up-sampling and YCbCr -> RGB run on the device (roma_jpeg_reconstruct) and leave a uint8 (height, width, 3) image for
  * roma_resample_u8 / roma_normalize_u8.  Bit-identical to PIL.  Supported: 8-bit baseline sequential Huffman, 1 or 3 components,
- * 4:4:4 or 4:2:0, one interleaved scan, restart intervals; anything else returns ROMA_E_UNSUPPORTED (decode with PIL on the host then).
- *   info[8]: width, height, components, sub-sampling (0: 4:4:4, 1: 4:2:0, -1: grey), luma blocks per row, luma block rows, chroma
+ * 4:4:4 / 4:2:2 / 4:2:0, one interleaved scan, restart intervals; anything else returns ROMA_E_UNSUPPORTED (decode with PIL on the host then).
+ *   info[8]: width, height, components, sub-sampling (0: 4:4:4, 1: 4:2:0, 2: 4:2:2, -1: grey), luma blocks per row, luma block rows, chroma
  *            blocks per row, chroma block rows;
  *   coef: int16, (luma + 2 x chroma blocks) x 64, natural order inside a block, blocks of a component in raster order, components
  *         one after the other; qt: 3 x 64 uint16, the component's de-quantisation table in natural order;

@@ -7,7 +7,8 @@ published algorithm is restated here and PINNED by comparing with PIL itself on 
 
 * inverse DCT: the "islow" integer transform (Loeffler-Ligtenberg-Moschytz, 13-bit constants, first pass scaled by 2^2), +128, clamp;
 * h2v2 "fancy" up-sampling: 3/4 nearer + 1/4 farther sample in each direction, biases 8 / 7 alternating along a row, edges replicated,
-  over ceil(W/2) x ceil(H/2) chroma samples (plain replication when there are at most two chroma columns);
+  over ceil(W/2) x ceil(H/2) chroma samples (plain replication when there are at most two chroma columns); for 4:2:2 the horizontal half
+  of it alone (biases 1 / 2, the first and last output column are the samples themselves);
 * YCbCr -> RGB with the 16-bit fixed-point constants 1.40200, 1.77200, 0.71414, 0.34414.
 """
 import numpy as np
@@ -58,6 +59,19 @@ def upsample_h2v2(p, W, H):
     return out[:H, :W]
 
 
+def upsample_h2v1(p, W, H):
+    """4:2:2: horizontal triangle filter only (biases 1 / 2; the first and last output column are the samples themselves)."""
+    cw = (W + 1) // 2
+    p = p[:H, :cw].astype(np.int64)
+    if cw <= 2:
+        return np.repeat(p, 2, axis=1)[:, :W]
+    left, right = np.hstack([p[:, :1], p[:, :-1]]), np.hstack([p[:, 1:], p[:, -1:]])
+    out = np.empty((H, 2 * cw), np.int64)
+    out[:, 0::2], out[:, 1::2] = (3 * p + left + 1) >> 2, (3 * p + right + 2) >> 2
+    out[:, 0], out[:, 2 * cw - 1] = p[:, 0], p[:, -1]
+    return out[:, :W]
+
+
 def reconstruct(coef, qt, info):
     """What roma_jpeg_reconstruct computes: coef (nblocks, 64) int16, qt (3, 64) uint16, info from roma_jpeg_info -> uint8 (H, W, 3)."""
     W, H, nc, sub, ybw, ybh, cbw, cbh = [int(v) for v in info]
@@ -69,6 +83,8 @@ def reconstruct(coef, qt, info):
     cr = idct_plane(coef[ny + ncb:ny + 2 * ncb], qt[2], cbw, cbh)
     if sub == 1:
         cb, cr = upsample_h2v2(cb, W, H), upsample_h2v2(cr, W, H)
+    elif sub == 2:
+        cb, cr = upsample_h2v1(cb, W, H), upsample_h2v1(cr, W, H)
     else:
         cb, cr = cb[:H, :W].astype(np.int64), cr[:H, :W].astype(np.int64)
     xb, xr = cb - 128, cr - 128

@@ -8,8 +8,8 @@
 // 13-bit constants and a 2-bit first-pass scale; the h2v2 "triangle" up-sampler, 3/4 near + 1/4 far in each direction with its 8 / 7
 // rounding biases and replicated edges; the 16-bit fixed-point colour tables), so the result is BIT-IDENTICAL to PIL's
 // (tests/test_jpeg.py: the four bundled photographs, one of them 618 pixels wide, and synthetic 4:4:4 / grey / restart-interval streams).
-// Supported: 8-bit baseline sequential (SOF0), Huffman, 1 or 3 components, 4:4:4 or 4:2:0, restart intervals.  Anything else
-// (progressive, 4:2:2, CMYK, 12-bit, arithmetic) is reported as ROMA_E_UNSUPPORTED and the caller decodes with PIL on the host.
+// Supported: 8-bit baseline sequential (SOF0), Huffman, 1 or 3 components, 4:4:4 / 4:2:2 / 4:2:0, restart intervals.  Anything else
+// (progressive, CMYK, RGB-stored, 12-bit, arithmetic) is reported as ROMA_E_UNSUPPORTED and the caller decodes with PIL on the host.
 #include <cstring>
 #include <vector>
 #include "common.h"
@@ -152,8 +152,9 @@ int parse(const uint8_t* d, size_t n, Header& H) {
       // sampling: grey, 4:4:4 or 4:2:0
       if (H.ncomp == 3) {
         const bool c444 = H.comp[0].h == 1 && H.comp[0].v == 1, c420 = H.comp[0].h == 2 && H.comp[0].v == 2;
-        if (!(c444 || c420) || H.comp[1].h != 1 || H.comp[1].v != 1 || H.comp[2].h != 1 || H.comp[2].v != 1) {
-          set_error("roma_jpeg: chroma sampling %dx%d,%dx%d,%dx%d (4:4:4 and 4:2:0 are decoded here)", H.comp[0].h, H.comp[0].v, H.comp[1].h,
+        const bool c422 = H.comp[0].h == 2 && H.comp[0].v == 1;
+        if (!(c444 || c420 || c422) || H.comp[1].h != 1 || H.comp[1].v != 1 || H.comp[2].h != 1 || H.comp[2].v != 1) {
+          set_error("roma_jpeg: chroma sampling %dx%d,%dx%d,%dx%d (4:4:4, 4:2:2 and 4:2:0 are decoded here)", H.comp[0].h, H.comp[0].v, H.comp[1].h,
                     H.comp[1].v, H.comp[2].h, H.comp[2].v);
           return ROMA_E_UNSUPPORTED;
         }
@@ -300,8 +301,21 @@ __global__ __launch_bounds__(256) void jpeg_rgb_kernel(const uint8_t* __restrict
   } else if (sub < 0) {
     cb = cr = 128;
   } else if (cw <= 2) {                                          // libjpeg picks the triangle filter only for more than two chroma columns
-    cb = cbp[(size_t)(y >> 1) * cpitch + (x >> 1)];
-    cr = crp[(size_t)(y >> 1) * cpitch + (x >> 1)];
+    const int yc = sub == 2 ? y : y >> 1;
+    cb = cbp[(size_t)yc * cpitch + (x >> 1)];
+    cr = crp[(size_t)yc * cpitch + (x >> 1)];
+  } else if (sub == 2) {
+    // 4:2:2, horizontal triangle filter only: column 2 j = (3 c[j] + c[j - 1] + 1) >> 2, column 2 j + 1 = (3 c[j] + c[j + 1] + 2) >> 2,
+    // the first and the last output column are the first / last sample themselves
+    const int j = x >> 1;
+    const uint8_t *r0 = cbp + (size_t)y * cpitch, *r1 = crp + (size_t)y * cpitch;
+    if ((x & 1) == 0) {
+      cb = j == 0 ? r0[0] : (3 * r0[j] + r0[j - 1] + 1) >> 2;
+      cr = j == 0 ? r1[0] : (3 * r1[j] + r1[j - 1] + 1) >> 2;
+    } else {
+      cb = j == cw - 1 ? r0[j] : (3 * r0[j] + r0[j + 1] + 2) >> 2;
+      cr = j == cw - 1 ? r1[j] : (3 * r1[j] + r1[j + 1] + 2) >> 2;
+    }
   } else {
     // output row 2 r + v takes 3/4 of chroma row r and 1/4 of row r - 1 (v = 0) or r + 1 (v = 1), edges replicated; output column
     // 2 j takes 3/4 of column j and 1/4 of column j - 1 with bias 8, column 2 j + 1 takes 1/4 of column j + 1 with bias 7; at the first
@@ -335,7 +349,7 @@ __global__ __launch_bounds__(256) void jpeg_rgb_kernel(const uint8_t* __restrict
 
 using namespace roma;
 
-// info[0..7] = width, height, components, chroma subsampling (0: 4:4:4, 1: 4:2:0, -1: grey), luma blocks per row, luma block rows, chroma
+// info[0..7] = width, height, components, chroma subsampling (0: 4:4:4, 1: 4:2:0, 2: 4:2:2, -1: grey), luma blocks per row, luma block rows, chroma
 // blocks per row, chroma block rows.  HOST function.
 extern "C" int roma_jpeg_info(const void* data, long nbytes, int* info) {
   ROMA_REQUIRE(data && info && nbytes > 0, ROMA_E_ARG, "roma_jpeg_info: null pointer");
@@ -344,7 +358,7 @@ extern "C" int roma_jpeg_info(const void* data, long nbytes, int* info) {
   const int mw = 8 * H.hmax, mh = 8 * H.vmax;
   const int mcux = (H.width + mw - 1) / mw, mcuy = (H.height + mh - 1) / mh;
   info[0] = H.width; info[1] = H.height; info[2] = H.ncomp;
-  info[3] = H.ncomp == 1 ? -1 : (H.hmax == 2 ? 1 : 0);
+  info[3] = H.ncomp == 1 ? -1 : (H.hmax == 2 ? (H.vmax == 2 ? 1 : 2) : 0);
   info[4] = mcux * H.hmax; info[5] = mcuy * H.vmax;
   info[6] = H.ncomp == 1 ? 0 : mcux; info[7] = H.ncomp == 1 ? 0 : mcuy;
   return 0;
