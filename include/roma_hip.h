@@ -267,12 +267,13 @@ int roma_add_layernorm(void* x, int x_dtype, long x_stride, const void* y, int y
 int roma_tiny_corr_posembed(const float* f0, const float* f1, float* out, int B, int C,
                             int H0, int W0, int H1, int W1, int exact, void* stream);
 
-/* Baseline JPEG decoding for match() on file paths — romatch/models/matcher.py:606-637, 667-676 (`Image.open(path).convert("RGB")`:
+/* JPEG decoding for match() on file paths — romatch/models/matcher.py:606-637, 667-676 (`Image.open(path).convert("RGB")`:
  * PIL -> libjpeg-turbo with its defaults, JDCT_ISLOW + fancy up-sampling).  The entropy-coded segment is decoded on the HOST
  * (roma_jpeg_info, roma_jpeg_entropy_decode: host functions, all pointers in host memory); de-quantisation + inverse DCT, chroma
  * up-sampling and YCbCr -> RGB run on the device (roma_jpeg_reconstruct) and leave a uint8 (height, width, 3) image for
- * roma_resample_u8 / roma_normalize_u8.  Bit-identical to PIL.  Supported: 8-bit baseline sequential Huffman, 1 or 3 components,
- * 4:4:4 / 4:2:2 / 4:2:0, one interleaved scan, restart intervals; anything else returns ROMA_E_UNSUPPORTED (decode with PIL on the host then).
+ * roma_resample_u8 / roma_normalize_u8.  Bit-identical to PIL.  Supported: 8-bit sequential (one interleaved scan) and progressive
+ * (spectral selection + successive approximation) Huffman streams, 1 or 3 components, 4:4:4 / 4:2:2 / 4:2:0, restart intervals; anything
+ * else (CMYK, RGB-stored, 12-bit, arithmetic, lossless) returns ROMA_E_UNSUPPORTED (decode with PIL on the host then).
  *   info[8]: width, height, components, sub-sampling (0: 4:4:4, 1: 4:2:0, 2: 4:2:2, -1: grey), luma blocks per row, luma block rows, chroma
  *            blocks per row, chroma block rows;
  *   coef: int16, (luma + 2 x chroma blocks) x 64, natural order inside a block, blocks of a component in raster order, components

@@ -8,8 +8,8 @@
 // 13-bit constants and a 2-bit first-pass scale; the h2v2 "triangle" up-sampler, 3/4 near + 1/4 far in each direction with its 8 / 7
 // rounding biases and replicated edges; the 16-bit fixed-point colour tables), so the result is BIT-IDENTICAL to PIL's
 // (tests/test_jpeg.py: the four bundled photographs, one of them 618 pixels wide, and synthetic 4:4:4 / grey / restart-interval streams).
-// Supported: 8-bit baseline sequential (SOF0), Huffman, 1 or 3 components, 4:4:4 / 4:2:2 / 4:2:0, restart intervals.  Anything else
-// (progressive, CMYK, RGB-stored, 12-bit, arithmetic) is reported as ROMA_E_UNSUPPORTED and the caller decodes with PIL on the host.
+// Supported: 8-bit baseline / extended sequential and PROGRESSIVE Huffman streams, 1 or 3 components, 4:4:4 / 4:2:2 / 4:2:0, restart
+// intervals.  Anything else (CMYK, RGB-stored, 12-bit, arithmetic, lossless) is reported as ROMA_E_UNSUPPORTED and the caller decodes with PIL on the host.
 #include <cstring>
 #include <vector>
 #include "common.h"
@@ -41,6 +41,9 @@ struct Header {
   size_t scan = 0;                                               // offset of the entropy-coded data
   int hmax = 1, vmax = 1;
   bool adobe_rgb = false, jfif = false;
+  bool progressive = false, sof = false;
+  // the scan the last SOS announced: its components (indices into comp), spectral band, successive-approximation bits
+  int sc_ns = 0, sc_ci[3] = {0, 0, 0}, Ss = 0, Se = 63, Ah = 0, Al = 0;
 };
 
 void build_huff(Huff& h, const uint8_t* counts, const uint8_t* vals, int nvals) {
@@ -68,12 +71,14 @@ void build_huff(Huff& h, const uint8_t* counts, const uint8_t* vals, int nvals) 
   h.present = true;
 }
 
-// parse the marker segments up to and including SOS; 0 or a negative roma error code
-int parse(const uint8_t* d, size_t n, Header& H) {
+// parse the marker segments from byte `i` (2: right behind SOI) up to and including the next SOS: 0 (H.scan = the entropy-coded data, the
+// scan's parameters in H), 1 = end of image (no further scan), or a negative roma error code
+int parse(const uint8_t* d, size_t n, Header& H, size_t i = 2) {
   if (n < 4 || d[0] != 0xFF || d[1] != 0xD8) { set_error("roma_jpeg: not a JPEG stream (no SOI)"); return ROMA_E_ARG; }
-  size_t i = 2;
-  bool sof = false;
-  while (i + 4 <= n) {
+  bool& sof = H.sof;
+  while (i + 2 <= n) {
+    if (d[i] == 0xFF && d[i + 1] == 0xD9) return 1;               // EOI
+    if (i + 4 > n) break;
     if (d[i] != 0xFF) { set_error("roma_jpeg: marker expected at byte %zu", i); return ROMA_E_ARG; }
     const int m = d[i + 1];
     if (m == 0xFF) { ++i; continue; }                            // fill byte
@@ -81,7 +86,8 @@ int parse(const uint8_t* d, size_t n, Header& H) {
     if (L < 2 || i + 2 + L > n) { set_error("roma_jpeg: truncated segment at byte %zu", i); return ROMA_E_ARG; }
     const uint8_t* s = d + i + 4;
     const size_t sl = L - 2;
-    if (m == 0xC0 || m == 0xC1) {                                // baseline / extended sequential Huffman
+    if (m == 0xC0 || m == 0xC1 || m == 0xC2) {                   // baseline / extended sequential / progressive, Huffman
+      H.progressive = m == 0xC2;
       if (sl < 6 || s[0] != 8) { set_error("roma_jpeg: %d-bit samples", sl ? s[0] : 0); return ROMA_E_UNSUPPORTED; }
       H.height = (s[1] << 8) | s[2];
       H.width = (s[3] << 8) | s[4];
@@ -96,8 +102,8 @@ int parse(const uint8_t* d, size_t n, Header& H) {
         H.vmax = std::max(H.vmax, H.comp[c].v);
       }
       sof = true;
-    } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
-      set_error("roma_jpeg: SOF%d (progressive / lossless / arithmetic) is not decoded here", m - 0xC0);
+    } else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+      set_error("roma_jpeg: SOF%d (lossless / arithmetic / hierarchical) is not decoded here", m - 0xC0);
       return ROMA_E_UNSUPPORTED;
     } else if (m == 0xDB) {                                      // quantisation tables (zig-zag order in the file)
       size_t o = 0;
@@ -124,20 +130,37 @@ int parse(const uint8_t* d, size_t n, Header& H) {
       if (sl >= 5 && memcmp(s, "JFIF", 4) == 0) H.jfif = true;
     } else if (m == 0xDD) {
       if (sl >= 2) H.restart = (s[0] << 8) | s[1];
-    } else if (m == 0xDA) {                                      // start of scan: one interleaved scan with all components
+    } else if (m == 0xDA) {                                      // start of scan
       if (!sof) { set_error("roma_jpeg: SOS before SOF"); return ROMA_E_ARG; }
-      if (sl < 1 || s[0] != H.ncomp || sl < 1 + 2 * (size_t)H.ncomp + 3) {
-        set_error("roma_jpeg: a scan with %d of %d components (non-interleaved scans are not decoded here)", sl ? s[0] : 0, H.ncomp);
+      const int ns = sl ? s[0] : 0;
+      if (ns < 1 || ns > H.ncomp || sl < 1 + 2 * (size_t)ns + 3) { set_error("roma_jpeg: bad SOS"); return ROMA_E_ARG; }
+      if (!H.progressive && ns != H.ncomp) {
+        set_error("roma_jpeg: a scan with %d of %d components (non-interleaved sequential scans are not decoded here)", ns, H.ncomp);
         return ROMA_E_UNSUPPORTED;
       }
-      for (int c = 0; c < H.ncomp; ++c) {
+      H.sc_ns = ns;
+      for (int c = 0; c < ns; ++c) {
         int ci = -1;
         for (int k = 0; k < H.ncomp; ++k)
           if (H.comp[k].id == s[1 + 2 * c]) ci = k;
-        if (ci != c) { set_error("roma_jpeg: scan component order"); return ROMA_E_UNSUPPORTED; }
-        H.comp[c].td = s[2 + 2 * c] >> 4;
-        H.comp[c].ta = s[2 + 2 * c] & 15;
-        if (!H.dc[H.comp[c].td].present || !H.ac[H.comp[c].ta].present || !H.qt_present[H.comp[c].tq]) {
+        if (ci < 0 || (c > 0 && ci <= H.sc_ci[c - 1])) { set_error("roma_jpeg: scan component order"); return ROMA_E_UNSUPPORTED; }
+        H.sc_ci[c] = ci;
+        H.comp[ci].td = s[2 + 2 * c] >> 4;
+        H.comp[ci].ta = s[2 + 2 * c] & 15;
+      }
+      H.Ss = s[1 + 2 * ns];
+      H.Se = s[2 + 2 * ns];
+      H.Ah = s[3 + 2 * ns] >> 4;
+      H.Al = s[3 + 2 * ns] & 15;
+      if (!H.progressive) { H.Ss = 0; H.Se = 63; H.Ah = H.Al = 0; }
+      if (H.Ss > H.Se || H.Se > 63 || H.Al > 13 || (H.Ss == 0 && H.Se != 0 && H.progressive) || (H.Ss > 0 && ns != 1)) {
+        set_error("roma_jpeg: bad progressive scan parameters");
+        return ROMA_E_ARG;
+      }
+      for (int c = 0; c < ns; ++c) {
+        const Comp& cp = H.comp[H.sc_ci[c]];
+        const bool need_dc = H.Ss == 0 && H.Ah == 0, need_ac = H.Se > 0;
+        if ((need_dc && !H.dc[cp.td].present) || (need_ac && !H.ac[cp.ta].present) || !H.qt_present[cp.tq]) {
           set_error("roma_jpeg: a table the scan refers to is missing");
           return ROMA_E_ARG;
         }
@@ -149,7 +172,7 @@ int parse(const uint8_t* d, size_t n, Header& H) {
         set_error("roma_jpeg: three components stored as RGB (no YCbCr transform) are not decoded here");
         return ROMA_E_UNSUPPORTED;
       }
-      // sampling: grey, 4:4:4 or 4:2:0
+      // sampling: grey, 4:4:4, 4:2:2 or 4:2:0
       if (H.ncomp == 3) {
         const bool c444 = H.comp[0].h == 1 && H.comp[0].v == 1, c420 = H.comp[0].h == 2 && H.comp[0].v == 2;
         const bool c422 = H.comp[0].h == 2 && H.comp[0].v == 1;
@@ -385,6 +408,129 @@ extern "C" int roma_jpeg_entropy_decode(const void* data, long nbytes, int16_t* 
     memcpy(qt + 64 * c, H.qt[H.comp[c].tq], 128);
   }
   memset(coef, 0, total * 64 * sizeof(int16_t));
+  if (H.progressive) {
+    // ---- progressive: every scan adds a spectral band and / or one more bit of precision to the coefficient array (ITU T.81 Annex G) ----
+    for (int nscan = 0; nscan < 1000; ++nscan) {
+      Bits b{d, (size_t)nbytes, H.scan};
+      const int ns = H.sc_ns, Ss = H.Ss, Se = H.Se, Ah = H.Ah, Al = H.Al;
+      const int p1 = 1 << Al, m1 = -(1 << Al);
+      // an interleaved scan (DC only) walks MCUs; a single-component scan walks that component's own blocks, ceil(width_c / 8) per row
+      int nbx = mcux, nby = mcuy;
+      if (ns == 1) {
+        const Comp& cp = H.comp[H.sc_ci[0]];
+        nbx = ((H.width * cp.h + H.hmax - 1) / H.hmax + 7) / 8;
+        nby = ((H.height * cp.v + H.vmax - 1) / H.vmax + 7) / 8;
+      }
+      int pred[3] = {0, 0, 0}, eobrun = 0, togo = H.restart;
+      for (int my = 0; my < nby; ++my)
+        for (int mx = 0; mx < nbx; ++mx) {
+          if (H.restart && togo == 0) {
+            size_t q = b.pos;
+            while (q + 1 < (size_t)nbytes && !(d[q] == 0xFF && d[q + 1] >= 0xD0 && d[q + 1] <= 0xD7)) ++q;
+            if (q + 1 >= (size_t)nbytes) { set_error("roma_jpeg: restart marker missing"); return ROMA_E_ARG; }
+            b.pos = q + 2;
+            b.reset();
+            pred[0] = pred[1] = pred[2] = 0;
+            eobrun = 0;
+            togo = H.restart;
+          }
+          for (int sc = 0; sc < ns; ++sc) {
+            const int c = H.sc_ci[sc];
+            const int nh = ns == 1 ? 1 : H.comp[c].h, nv = ns == 1 ? 1 : H.comp[c].v;
+            for (int v = 0; v < nv; ++v)
+              for (int h = 0; h < nh; ++h) {
+                int16_t* blk = coef + (off[c] + (size_t)(my * nv + v) * bw[c] + mx * nh + h) * 64;
+                if (Ss == 0) {                                   // DC: first pass or one more bit
+                  if (Ah == 0) {
+                    const int sz = decode_sym(b, H.dc[H.comp[c].td]);
+                    if (sz < 0 || sz > 15) { set_error("roma_jpeg: corrupt DC code"); return ROMA_E_ARG; }
+                    b.fill();
+                    if (sz) pred[c] += extend(b.get(sz), sz);
+                    blk[0] = (int16_t)(pred[c] * p1);
+                  } else {
+                    b.fill();
+                    if (b.get(1)) blk[0] |= (int16_t)p1;
+                  }
+                  continue;
+                }
+                const Huff& ha = H.ac[H.comp[c].ta];
+                if (Ah == 0) {                                   // AC band, first pass
+                  if (eobrun > 0) { --eobrun; continue; }
+                  for (int k = Ss; k <= Se;) {
+                    const int rs = decode_sym(b, ha);
+                    if (rs < 0) { set_error("roma_jpeg: corrupt AC code"); return ROMA_E_ARG; }
+                    const int r = rs >> 4, sz = rs & 15;
+                    if (sz == 0) {
+                      if (r < 15) {                              // end of band for 2^r + bits blocks, this one included
+                        eobrun = (1 << r) - 1;
+                        if (r) { b.fill(); eobrun += b.get(r); }
+                        break;
+                      }
+                      k += 16;
+                      continue;
+                    }
+                    k += r;
+                    if (k > Se) { set_error("roma_jpeg: AC run past the band"); return ROMA_E_ARG; }
+                    b.fill();
+                    blk[kZigzag[k]] = (int16_t)(extend(b.get(sz), sz) * p1);
+                    ++k;
+                  }
+                  continue;
+                }
+                // AC band, refinement: one correction bit for every coefficient that is already non-zero, new +-2^Al coefficients
+                // placed after `r` still-zero positions (the decoder of Annex G.1.2.3)
+                int k = Ss;
+                if (eobrun == 0) {
+                  for (; k <= Se; ++k) {
+                    const int rs = decode_sym(b, ha);
+                    if (rs < 0) { set_error("roma_jpeg: corrupt AC code"); return ROMA_E_ARG; }
+                    int r = rs >> 4, val = rs & 15;
+                    if (val) {
+                      b.fill();
+                      val = b.get(1) ? p1 : m1;
+                    } else if (r != 15) {
+                      eobrun = 1 << r;
+                      if (r) { b.fill(); eobrun += b.get(r); }
+                      break;
+                    }
+                    do {
+                      int16_t* cf = blk + kZigzag[k];
+                      if (*cf != 0) {
+                        b.fill();
+                        if (b.get(1) && (*cf & p1) == 0) *cf = (int16_t)(*cf + (*cf >= 0 ? p1 : m1));
+                      } else if (--r < 0) {
+                        break;
+                      }
+                      ++k;
+                    } while (k <= Se);
+                    if (val && k <= Se) blk[kZigzag[k]] = (int16_t)val;
+                  }
+                }
+                if (eobrun > 0) {
+                  for (; k <= Se; ++k) {
+                    int16_t* cf = blk + kZigzag[k];
+                    if (*cf != 0) {
+                      b.fill();
+                      if (b.get(1) && (*cf & p1) == 0) *cf = (int16_t)(*cf + (*cf >= 0 ? p1 : m1));
+                    }
+                  }
+                  --eobrun;
+                }
+              }
+          }
+          if (H.restart) --togo;
+        }
+      // the next marker segment: further tables and scans, or the end of the image
+      size_t q = b.pos;
+      while (q + 1 < (size_t)nbytes && !(d[q] == 0xFF && d[q + 1] != 0 && !(d[q + 1] >= 0xD0 && d[q + 1] <= 0xD7) && d[q + 1] != 0xFF)) ++q;
+      if (q + 1 >= (size_t)nbytes) break;                        // no EOI: what has been decoded stands (libjpeg warns and does the same)
+      const int rc = parse(d, (size_t)nbytes, H, q);
+      if (rc == 1) break;
+      if (rc < 0) return rc;
+    }
+    for (int c = 0; c < H.ncomp; ++c) memcpy(qt + 64 * c, H.qt[H.comp[c].tq], 128);
+    return 0;
+  }
   Bits b{d, (size_t)nbytes, H.scan};
   int pred[3] = {0, 0, 0};
   int togo = H.restart;

@@ -494,7 +494,7 @@ class RegressionMatcher(nn.Module):
         self.symmetric = symmetric
         self.sample_thresh = 0.05
         self.host_preprocess = False          # True: PIL resize on the host like the reference (same bits, slower)
-        self.device_jpeg = True               # baseline JPEG paths: entropy decoding on the host, IDCT / up-sampling / RGB on the device (same bits as PIL)
+        self.device_jpeg = True               # JPEG paths: entropy decoding on the host, IDCT / up-sampling / RGB on the device (same bits as PIL)
 
     def get_output_resolution(self):
         return self.upsample_res if self.upsample_preds else (self.h_resized, self.w_resized)
@@ -720,7 +720,7 @@ class RegressionMatcher(nn.Module):
         for im in (im_A_input, im_B_input):
             if isinstance(im, (str, os.PathLike)):
                 if not getattr(self, "host_preprocess", False) and getattr(self, "device_jpeg", True):
-                    # baseline JPEG files: Huffman decoding on the host, everything after it on the device, bit-identical to PIL
+                    # JPEG files: Huffman decoding on the host, everything after it on the device, bit-identical to PIL
                     # (preproc.decode_jpeg_device; None = a stream the kernels do not cover -> PIL below)
                     from .preproc import decode_jpeg_device
                     dec = decode_jpeg_device(im, device) if str(im).lower().endswith((".jpg", ".jpeg")) else None

@@ -127,8 +127,8 @@ def decode_jpeg_device(data, device):
     """JPEG bytes (or a path) -> uint8 (H, W, 3) RGB tensor on `device`, bit-identical to `np.array(Image.open(..).convert("RGB"))`
     (matcher.py:606-637, 667-676).  The Huffman decoding runs on the host (roma_jpeg_entropy_decode), de-quantisation + inverse DCT +
     chroma up-sampling + colour conversion on the GPU (roma_jpeg_reconstruct): only the quantised coefficients cross PCIe.
-    Returns None for streams the kernels do not cover (progressive, 4:2:2, CMYK / RGB-stored, 12-bit, arithmetic coding): decode those with
-    PIL.  The pinned staging buffer is one per process and guarded by one event: call from one thread at a time."""
+    Sequential and progressive Huffman streams, grey or YCbCr 4:4:4 / 4:2:2 / 4:2:0.  Returns None for what is not covered (CMYK / RGB-stored,
+    12-bit, arithmetic coding, lossless): decode those with PIL.  The pinned staging buffer is one per process and guarded by one event: call from one thread at a time."""
     import os
     from . import _lib
     from ._lib import check

@@ -32,7 +32,8 @@ def _host_decode(data):
 
 
 def _synthetic_jpegs():
-    """Streams the bundled photographs do not cover: 4:4:4, grey, odd sizes, restart intervals, optimised Huffman tables."""
+    """Streams the bundled photographs do not cover: 4:4:4, 4:2:2, grey, odd sizes, restart intervals, optimised Huffman tables, and
+    PROGRESSIVE streams (spectral selection + successive approximation; a bundled photograph re-encoded that way)."""
     rng = np.random.default_rng(11)
     yy, xx = np.mgrid[0:97, 0:131]
     base = np.stack([127 + 100 * np.sin(xx / 9.0) * np.cos(yy / 7.0), 127 + 90 * np.cos(xx / 5.0 + yy / 11.0), 40 + 1.5 * xx], axis=2)
@@ -46,7 +47,13 @@ def _synthetic_jpegs():
                          ("tiny", Image.fromarray(img[:5, :3]), dict(subsampling=2, quality=95)),
                          ("422", Image.fromarray(img), dict(subsampling=1, quality=85)),
                          ("422_odd", Image.fromarray(img[:33, :61]), dict(subsampling=1, quality=70)),
-                         ("422_tiny", Image.fromarray(img[:9, :4]), dict(subsampling=1, quality=90))]:
+                         ("422_tiny", Image.fromarray(img[:9, :4]), dict(subsampling=1, quality=90)),
+                         ("prog_420", Image.fromarray(img), dict(progressive=True, quality=80)),
+                         ("prog_444", Image.fromarray(img), dict(progressive=True, subsampling=0, quality=92)),
+                         ("prog_422_odd", Image.fromarray(img[:95, :129]), dict(progressive=True, subsampling=1, quality=60)),
+                         ("prog_grey", Image.fromarray(img[..., 0]), dict(progressive=True, quality=85)),
+                         ("prog_rst", Image.fromarray(img), dict(progressive=True, quality=75, restart_marker_blocks=4)),
+                         ("prog_photo", Image.open(ASSETS[1]).convert("RGB"), dict(progressive=True, quality=88, optimize=True))]:
         bio = io.BytesIO()
         try:
             im.save(bio, "JPEG", **kw)
@@ -60,7 +67,7 @@ def test_host_entropy_decoder_and_restatement_are_bit_identical_to_pil():
     from oracle import jpeg_oracle
     streams = {os.path.basename(f): open(f, "rb").read() for f in ASSETS}
     streams.update(_synthetic_jpegs())
-    assert len(streams) >= 11
+    assert len(streams) >= 16
     for name, data in streams.items():
         rc, info, coef, qt = _host_decode(data)
         assert rc == 0, (name, rc, _lib.load().roma_last_error())
@@ -69,13 +76,12 @@ def test_host_entropy_decoder_and_restatement_are_bit_identical_to_pil():
         assert mine.shape == ref.shape and np.array_equal(mine, ref), name
 
 
-def test_streams_outside_the_baseline_subset_are_refused_not_misdecoded():
+def test_streams_outside_the_supported_subset_are_refused_not_misdecoded():
     img = Image.fromarray((np.arange(64 * 64 * 3) % 251).astype(np.uint8).reshape(64, 64, 3))
-    for kw in (dict(progressive=True),):                        # progressive
-        bio = io.BytesIO()
-        img.save(bio, "JPEG", **kw)
-        rc, *_ = _host_decode(bio.getvalue())
-        assert rc == _lib.ROMA_E_UNSUPPORTED, kw
+    bio = io.BytesIO()
+    img.convert("CMYK").save(bio, "JPEG")                       # four components
+    rc, *_ = _host_decode(bio.getvalue())
+    assert rc == _lib.ROMA_E_UNSUPPORTED
     bio = io.BytesIO()
     try:
         img.save(bio, "JPEG", keep_rgb=True)                    # three components stored as RGB (Adobe marker, no YCbCr transform)
@@ -101,7 +107,7 @@ def test_device_reconstruction_is_bit_identical_to_pil():
         ref = torch.from_numpy(np.array(Image.open(io.BytesIO(data)).convert("RGB")))
         assert rgb.shape == ref.shape and torch.equal(rgb.cpu(), ref), name
     bio = io.BytesIO()
-    Image.fromarray(np.zeros((32, 32, 3), np.uint8)).save(bio, "JPEG", progressive=True)
+    Image.fromarray(np.zeros((32, 32, 3), np.uint8)).convert("CMYK").save(bio, "JPEG")
     assert decode_jpeg_device(bio.getvalue(), "cuda") is None  # the caller decodes such a stream with PIL
     assert torch.equal(decode_jpeg_device(ASSETS[1], "cuda").cpu(), torch.from_numpy(np.array(Image.open(ASSETS[1]).convert("RGB"))))   # a path
 
